@@ -1,0 +1,146 @@
+/*
+ * tvl.h - C ABI of libternary_hip.so: ternary / binary quantized matmul for AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  Each entry point names the reference interface it stands in
+ * for (paths relative to the reference repository).  The reference's native operator sources
+ * (native/tensorflow_custom_ops/cc) are not in its tree, and its packed ops come from an external
+ * larq_compute_engine fork, so "replaces" means: same operator name, same argument meaning, the
+ * arithmetic of the reference's Python layers.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says otherwise; the caller owns all
+ *     buffers (inputs and outputs); the library allocates nothing and keeps no pointer.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - return value 0 = success.  TVL_ERR_INVALID = a bad argument (shape, dtype, alignment,
+ *     NULL pointer): nothing was launched.  TVL_ERR_HIP = the HIP runtime reported an error.
+ *     tvl_last_error() returns a description for the calling thread's last failure.
+ *   - matrices are row-major; `ld_*` is the distance between rows IN ELEMENTS of that matrix
+ *     (bytes for packed weights).  ld = 0 means "dense" (the natural row length).
+ *   - packed weights ("format C"): uint8 [N, ld_pw >= ceil(K/4)], byte [n, j] holds weights
+ *     k = 4j..4j+3 of output channel n, weight i in bits [2i+1:2i], code = value + 1
+ *     (-1 -> 0, 0 -> 1, +1 -> 2; code 3 decodes to +2 exactly like the reference's
+ *     `((b >> 2i) & 3) - 1`).  impl/tf/moondream/ternary.py:374-398 (pack), :507-520 (decode).
+ */
+#ifndef TVL_H_
+#define TVL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TVL_VERSION 100 /* 0.1.0 */
+
+enum { TVL_OK = 0, TVL_ERR_INVALID = 1, TVL_ERR_HIP = 2 };
+
+/* element types of activations / outputs */
+enum { TVL_F32 = 0, TVL_F16 = 1, TVL_BF16 = 2, TVL_I8 = 3, TVL_I32 = 4 };
+
+/* weight quantizers.  binary/modules.py:21-26 (ternary), :5-10 (sign), :13-18 (step) */
+enum { TVL_Q_TERNARY = 0, TVL_Q_SIGN = 1, TVL_Q_STEP = 2 };
+
+/* activation fused after the clip.  GELU-tanh is what the reference attaches to fc1
+ * (utils/conversion.py:185-187); it is applied after the op at impl/tf/moondream/ternary.py:298-299. */
+enum { TVL_ACT_NONE = 0, TVL_ACT_GELU_TANH = 1 };
+
+/* planar 1-D layouts of the pure-TF layer.  impl/tf/moondream/ternary.py:57-78 (A), :114-133 (B) */
+enum { TVL_PLANAR_A = 0, TVL_PLANAR_B = 1 };
+
+int tvl_version(void);
+/* Host string, valid until the calling thread's next failing call. */
+const char* tvl_last_error(void);
+/* Host string describing the build (target arch, kernels). */
+const char* tvl_build_info(void);
+
+/* ---- quantize + pack (one-time, HBM-bound) ------------------------------------------------- */
+
+/* Quantize latent weights w [n,k] (f32 / f16 / bf16) and pack them 2 bits each into pw.
+ * mode TVL_Q_TERNARY: (w >= thr) - (w <= -thr), thresholds inclusive.
+ * Replaces `ops.pack_fn(tf.cast(ternary_act(w), tf.int8))` at utils/conversion.py:71-72 and the
+ * per-forward `tri_step_ste(self.weights)` at binary/modules.py:102.  Pad bits (k..4*ceil(k/4))
+ * are written as code 1 (value 0); bytes beyond ceil(k/4) in a row are left untouched. */
+int tvl_quantize_pack(const void* w, int w_dtype, int64_t n, int64_t k, int64_t ld_w, int mode,
+                      float threshold, uint8_t* pw, int64_t ld_pw, void* stream);
+
+/* Pack already-quantized int8 values in {-1,0,+1} (code = value + 1, low two bits).
+ * Replaces `ops.pack_fn(int8 [N,K])` (utils/conversion.py:72) / ScaledTernaryPackedMM.pack_fn
+ * (impl/tf/moondream/ternary.py:374-398). */
+int tvl_pack_i8(const int8_t* t, int64_t n, int64_t k, int64_t ld_t, uint8_t* pw, int64_t ld_pw,
+                void* stream);
+
+/* Unpack pw [n, ld_pw] to out [n, k] of out_dtype (f32 / f16 / bf16 / i8) holding {-1,0,+1,(+2)}.
+ * Replaces `ops.unpack_ternary(pw, orig_dim)` at impl/tf/moondream/ternary.py:334. */
+int tvl_unpack(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, void* out, int out_dtype,
+               int64_t ld_out, void* stream);
+
+/* Planar 1-D layouts A and B of ScaledTernaryTf: `len` int8 values -> ceil(len/4) bytes, and back
+ * (4*packed_len values; the caller slices the first `len`).
+ * Replaces pack_ternary / pack_ternary2 / unpack_ternary_iterative / unpack_ternary_iterative2
+ * at impl/tf/moondream/ternary.py:57-78, :114-133, :101-110, :136-156. */
+int tvl_pack_planar_i8(const int8_t* t, int64_t len, int format, uint8_t* pw, void* stream);
+int tvl_unpack_planar(const uint8_t* pw, int64_t packed_len, int format, void* out, int out_dtype,
+                      void* stream);
+
+/* Dense quantizer: out[i] = q(w[i]) in the dtype of w (f32 / f16 / bf16) or int8 (out_dtype).
+ * Replaces tri_step_ste / sign_ste / step_ste (binary/modules.py:5-26) as a forward value. */
+int tvl_quantize(const void* w, int w_dtype, int64_t numel, int mode, float threshold, void* out,
+                 int out_dtype, void* stream);
+
+/* ---- the fused op ---------------------------------------------------------------------------- */
+
+/* y[m,n] = act(clip((x[m,k] @ unpack(pw)[n,k]^T) * scale[n] + bias[n], -|clip|, +|clip|))
+ * x: f16 / bf16 / f32 [m, ld_x]; y: f16 / bf16 / f32 [m, ld_y]; scale, bias: f32 [n] (bias may be
+ * NULL).  Accumulation in float32; the epilogue is one f32 multiply, one f32 add (not fused), the
+ * clip, the optional activation, then one rounding to y's type.
+ * Replaces `ops.ternary_matmul(x, pw, scale, bias, clip)` at impl/tf/moondream/ternary.py:281 and
+ * ScaledTernaryLinear.forward at binary/modules.py:101-109.
+ * `workspace` (device, may be NULL) lets the library pick kernels that need scratch memory
+ * (split-K partial sums); see tvl_ternary_matmul_workspace_bytes. */
+int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x,
+                       const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
+                       const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y,
+                       void* workspace, size_t workspace_bytes, void* stream);
+size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k);
+
+/* Multiplication-free select-and-sum with DENSE float weights: res[m, i] = sum_{tm[i,k]>0} x[m,k]
+ * - sum_{tm[i,k]<0} x[m,k].  Replaces ternary_mm at matrix_mul_tests.py:29-37 (f32 only). */
+int tvl_ternary_mm_f32(const float* x, int64_t m, int64_t k, int64_t ld_x, const float* tm,
+                       int64_t n, int64_t ld_tm, float* res, int64_t ld_res, void* stream);
+
+/* ---- scale fits (one-time) -------------------------------------------------------------------- */
+
+/* Ternary scale by the reference's masked-mean fixed point (binary/modules.py:280-293):
+ * m0 = mean|w|; `iters` times: mask = |w| > m/2, m = sum(|w| mask)/count(mask).
+ * uniform = 0: one m per row; uniform != 0: one m for the whole matrix (neuron_scale="uniform").
+ * Writes scale[n] = m and, if latent != NULL, latent[n,k] = clip(w * (1/m), -1, 1).
+ * workspace: tvl_fit_scale_workspace_bytes(n, k) bytes of device memory. */
+int tvl_fit_ternary_scale_f32(const float* w, int64_t n, int64_t k, int64_t ld_w, int uniform,
+                              int iters, float* scale, float* latent, int64_t ld_latent,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* Binary scales (binary/modules.py:197-210, :236-245): mode TVL_Q_SIGN: (sum_{w>0} w - sum_{w<0} w)
+ * / count; TVL_Q_STEP: sum_{w>0} w / count; count = n*k (uniform) or k (per row).
+ * latent (optional) = clip(w * prescale, -1, 1) with prescale = `prescale` when natural == 0, or
+ * 1/scale[row] when natural != 0 (scaling="natural", :221-222). */
+int tvl_fit_binary_scale_f32(const float* w, int64_t n, int64_t k, int64_t ld_w, int mode,
+                             int uniform, float prescale, int natural, float* scale, float* latent,
+                             int64_t ld_latent, void* workspace, size_t workspace_bytes,
+                             void* stream);
+size_t tvl_fit_scale_workspace_bytes(int64_t n, int64_t k);
+
+/* ---- plumbing ops of the reference's op library ------------------------------------------------ */
+
+/* out[0] = in[0], out[1..numel) = 0.  Replaces zero_out (custom_ops_mod.py:29). */
+int tvl_zero_out_i32(const int32_t* in, int64_t numel, int32_t* out, void* stream);
+/* out = constant (uint8 copy); `witness` is accepted and ignored: on this stack nothing folds
+ * constants, the op exists so callers keep working.  Replaces prevent_folding
+ * (custom_ops_mod.py:30; Python twin impl/tf/moondream/ternary.py:28-30). */
+int tvl_prevent_folding_u8(const uint8_t* constant, int64_t numel, const void* witness,
+                           uint8_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TVL_H_ */

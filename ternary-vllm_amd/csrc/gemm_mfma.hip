@@ -1,0 +1,275 @@
+// Packed-ternary x f16/bf16 GEMM on the gfx950 matrix cores.
+//
+//   y[m,n] = act(clip((sum_k x[m,k] * (code(pw[n,k]) - 1)) * scale[n] + bias[n]))
+//
+// Design (MI355X):
+//  * the activation tile goes global -> LDS directly (global_load_lds, 16 B per lane), double
+//    buffered, one barrier per 64-deep k step; the LDS image is XOR-swizzled through the SOURCE
+//    address (LDS-DMA writes lane-linear) so the 32-row fragment reads (ds_read_b128) are
+//    conflict-free;
+//  * the packed weights never touch LDS: each lane loads the 8 bytes (32 weights) of its own
+//    output channel for the step straight into registers and decodes them there, 2 bits ->
+//    f16 {-1,0,+1,+2}, with the mantissa trick  (bits | 0x6400) = 1024 + c * 4^j  followed by one
+//    packed fma  v * 4^-j - (1024 * 4^-j + 1)  -- exact, ~1.25 VALU ops per weight, reused over
+//    the wave's 4 (or 2) row tiles;
+//  * the k order inside a 64-step is permuted identically for both operands (lane half h takes
+//    k = 32h .. 32h+31) so that each lane's weight bytes are contiguous;
+//  * v_mfma_f32_32x32x16_{f16,bf16}, float32 accumulators, fused scale / bias / clip / GELU
+//    epilogue straight from the accumulator registers.
+// Requires k % 64 == 0, 16-byte aligned activation rows and 8-byte aligned packed rows; any m, n
+// (edge tiles clamp their loads and mask their stores).
+#include "tvl_common.h"
+#include "tvl_kernels.h"
+
+namespace tvl {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int BK = 64;             // k elements per pipeline step
+constexpr int ROW_BYTES = BK * 2;  // bytes of one activation row in the LDS tile
+
+// ---- 2-bit -> f16 decode -------------------------------------------------------------------
+// `d` holds 16 codes; BYTE selects 4 of them (weights 4*BYTE .. 4*BYTE+3 of the dword).
+// Returns two registers: (w0, w1) and (w2, w3) as packed f16.
+template <int BYTE>
+__device__ __forceinline__ void decode4_f16(uint32_t d, uint32_t& r01, uint32_t& r23) {
+    // rep = [byte, 0, byte, 0]: the selected byte in the low 8 bits of both 16-bit halves
+    const uint32_t rep = __builtin_amdgcn_perm(d, d, 0x0C000C00u | BYTE | (BYTE << 16));
+    const uint32_t v01 = (rep & 0x000C0003u) | 0x64006400u;  // lo = 1024 + c0      hi = 1024 + 4 c1
+    const uint32_t v23 = (rep & 0x00C00030u) | 0x64006400u;  // lo = 1024 + 16 c2   hi = 1024 + 64 c3
+    const half2v m01 = {(_Float16)1.0f, (_Float16)0.25f}, a01 = {(_Float16)-1025.0f, (_Float16)-257.0f};
+    const half2v m23 = {(_Float16)0.0625f, (_Float16)0.015625f}, a23 = {(_Float16)-65.0f, (_Float16)-17.0f};
+    const half2v o01 = __builtin_elementwise_fma(__builtin_bit_cast(half2v, v01), m01, a01);
+    const half2v o23 = __builtin_elementwise_fma(__builtin_bit_cast(half2v, v23), m23, a23);
+    r01 = __builtin_bit_cast(uint32_t, o01);
+    r23 = __builtin_bit_cast(uint32_t, o23);
+}
+
+// f16 bit patterns of {-1,0,1,2} -> bf16 bit patterns of the same values, two per register
+__device__ __forceinline__ uint32_t f16pair_to_bf16pair(uint32_t f) { return f | ((f >> 3) & 0x03800380u); }
+
+// 8 weights (one halfword: HW = 0..1 of the dword) -> one MFMA B fragment
+template <typename TX, int HW>
+__device__ __forceinline__ uint4 decode8(uint32_t d) {
+    uint4 r;
+    decode4_f16<2 * HW>(d, r.x, r.y);
+    decode4_f16<2 * HW + 1>(d, r.z, r.w);
+    if constexpr (sizeof(TX) == 2 && !__is_same(TX, f16)) {
+        r.x = f16pair_to_bf16pair(r.x); r.y = f16pair_to_bf16pair(r.y);
+        r.z = f16pair_to_bf16pair(r.z); r.w = f16pair_to_bf16pair(r.w);
+    }
+    return r;
+}
+
+template <typename TX>
+__device__ __forceinline__ floatx16 mfma32(uint4 a, uint4 b, floatx16 c) {
+    if constexpr (__is_same(TX, f16)) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+}
+
+// XCD-aware tile order: blocks with equal (blockIdx % 8) share an XCD (and its L2) under the
+// observed round-robin placement; give each such group a contiguous run of tiles in row-major
+// order so that a group streams whole activation row panels once.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return start + i;
+}
+
+template <typename TX, typename TY, int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_BIAS, int ACT>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
+gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
+                 const float* __restrict__ scale, const float* __restrict__ bias, float clip, TY* __restrict__ y,
+                 int64_t ld_y, int tiles_n, int nblk) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;            // 32x32 MFMA tiles per wave
+    constexpr int A_TILE_BYTES = BM * ROW_BYTES;
+    constexpr int ROUNDS = (BM * 8) / NT;                // 16-byte pieces per thread per tile
+    static_assert((BM * 8) % NT == 0, "tile/threads mismatch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * A_TILE_BYTES
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wid / WAVES_N, wc = wid % WAVES_N;
+    const int tile = xcd_remap(blockIdx.x, nblk);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    // ---- activation staging addresses (per thread, constant over k) ----------------------
+    const TX* a_src[ROUNDS];
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+        const int p = i * NT + tid;           // 16-byte piece index inside the tile image
+        const int row = p >> 3, cs = p & 7;   // LDS row, swizzled chunk
+        const int chunk = cs ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < m ? gm : m - 1;
+        a_src[i] = x + (int64_t)gm * ld_x + chunk * 8;
+    }
+    auto stage_a = [&](int kb, int buf) {
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) {
+            unsigned char* dst = lds + buf * A_TILE_BYTES + (i * NT + wid * 64) * 16;  // wave-uniform
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (int64_t)kb * BK), (lptr_t)dst, 16, 0, 0);
+        }
+    };
+
+    // ---- packed weight addresses ------------------------------------------------------------
+    const uint8_t* b_src[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        int gn = n0 + wc * WN + t * 32 + r;
+        gn = gn < n ? gn : n - 1;
+        b_src[t] = pw + (int64_t)gn * ld_pw + 8 * h;
+    }
+
+    // ---- fragment read offsets -----------------------------------------------------------------
+    const int sw = (r >> 1) & 7;
+    const int a_row_off = (wr * WM + r) * ROW_BYTES;
+    int a_col_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a_col_off[s] = ((4 * h + s) ^ sw) * 16;
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.0f;
+
+    const int nk = k / BK;
+    uint2 bq[TN], bq_next[TN];
+    stage_a(0, 0);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) bq_next[t] = bq[t] = *reinterpret_cast<const uint2*>(b_src[t]);
+
+    for (int kb = 0; kb < nk; ++kb) {
+        // the tile for this step was issued one step ago; every wave drains its own LDS-DMA, then
+        // the barrier makes all pieces visible and retires the reads of the buffer refilled below
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kb + 1 < nk) {
+            stage_a(kb + 1, (kb + 1) & 1);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) bq_next[t] = *reinterpret_cast<const uint2*>(b_src[t] + (int64_t)(kb + 1) * (BK / 4));
+        }
+        const unsigned char* abase = lds + (kb & 1) * A_TILE_BYTES + a_row_off;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const uint4*>(abase + i * 32 * ROW_BYTES + a_col_off[s]);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const uint32_t d = (s < 2) ? bq[t].x : bq[t].y;
+                bf[t] = (s & 1) ? decode8<TX, 1>(d) : decode8<TX, 0>(d);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int t = 0; t < TN; ++t) acc[i][t] = mfma32<TX>(af[i], bf[t], acc[i][t]);
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bq[t] = bq_next[t];
+    }
+
+    // ---- epilogue: lane owns column n = .. + r, rows (e&3) + 8 (e>>2) + 4 h ---------------------
+    const float c = fabsf(clip);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int gn = n0 + wc * WN + t * 32 + r;
+        if (gn >= n) continue;
+        const float sc = scale[gn];
+        const float bi = HAS_BIAS ? bias[gn] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int gm = m0 + wr * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (gm < m) y[(int64_t)gm * ld_y + gn] = from_float<TY>(epilogue<HAS_BIAS, ACT>(acc[i][t][e], sc, bi, c));
+            }
+        }
+    }
+}
+
+template <typename TX, typename TY, int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                      const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
+    const int tiles_m = (int)ceil_div(m, BM), tiles_n = (int)ceil_div(n, BN);
+    const int nblk = tiles_m * tiles_n;
+    const size_t lds_bytes = 2 * BM * ROW_BYTES;
+    const dim3 grid(nblk), block(64 * WAVES_M * WAVES_N);
+#define TVL_GM(HB, ACT)                                                                                            \
+    do {                                                                                                           \
+        auto kern = gemm_mfma_kernel<TX, TY, BM, BN, WAVES_M, WAVES_N, HB, ACT>;                                    \
+        if (lds_bytes > 48 * 1024)                                                                                 \
+            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, y, \
+                           ld_y, tiles_n, nblk);                                                                   \
+    } while (0)
+    if (bias) {
+        if (act == TVL_ACT_GELU_TANH) TVL_GM(true, TVL_ACT_GELU_TANH); else TVL_GM(true, TVL_ACT_NONE);
+    } else {
+        if (act == TVL_ACT_GELU_TANH) TVL_GM(false, TVL_ACT_GELU_TANH); else TVL_GM(false, TVL_ACT_NONE);
+    }
+#undef TVL_GM
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+template <typename TX, typename TY>
+static int launch_mfma_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                          const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
+    // 256x256 tiles when they fill the chip (>= ~1 tile per CU), else smaller tiles
+    const int64_t big_tiles = ceil_div(m, 256) * ceil_div(n, 256);
+    if (big_tiles >= 192)
+        return launch_cfg<TX, TY, 256, 256, 2, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
+    if (m > 64)
+        return launch_cfg<TX, TY, 128, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
+    if (m > 32)
+        return launch_cfg<TX, TY, 64, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
+    return launch_cfg<TX, TY, 32, 128, 1, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
+}
+
+template <typename TX>
+static int launch_mfma_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                         const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y,
+                         hipStream_t st) {
+    switch (y_dtype) {
+        case TVL_F32: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (float*)y, ld_y, st);
+        case TVL_F16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (f16*)y, ld_y, st);
+        case TVL_BF16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (bf16_t*)y, ld_y, st);
+        default: set_error("ternary_matmul: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
+    }
+}
+
+bool gemm_mfma_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
+                         int64_t ld_pw) {
+    if (x_dtype != TVL_F16 && x_dtype != TVL_BF16) return false;
+    if (k % BK != 0 || k <= 0) return false;
+    if (!aligned(x, 16) || (ld_x * 2) % 16 != 0) return false;
+    if (!aligned(pw, 8) || ld_pw % 8 != 0) return false;
+    if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return false;
+    if (ceil_div(m, 128) * ceil_div(n, 128) > INT32_MAX) return false;
+    return true;
+}
+
+int launch_gemm_mfma(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
+                     int64_t ld_pw, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype,
+                     int64_t ld_y, hipStream_t st) {
+    if (x_dtype == TVL_F16) return launch_mfma_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
+    return launch_mfma_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
+}
+
+}  // namespace tvl

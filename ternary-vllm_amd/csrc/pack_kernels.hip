@@ -1,0 +1,359 @@
+// Quantize / pack / unpack kernels (HBM-bound byte and bit work) for gfx950.
+//
+// Packed layout ("format C", impl/tf/moondream/ternary.py:374-398): byte [n, j] holds weights
+// k = 4j..4j+3, weight i in bits [2i+1:2i], code = value + 1.
+#include "tvl_common.h"
+#include "tvl_kernels.h"
+
+namespace tvl {
+
+// ---- quad OR-reduction through DPP (lanes 4q..4q+3 end up holding the same dword) ------------
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) {
+    // quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E ; all rows/banks enabled
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
+    return v;
+}
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<f16> { using type = uint2; };
+template <> struct Vec4<bf16_t> { using type = uint2; };
+
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&o)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> __device__ __forceinline__ void load4<f16>(const f16* p, float (&o)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    const f16* h = reinterpret_cast<const f16*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (float)h[i];
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&o)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xFFFF0000u);
+}
+
+// Fast quantize+pack: one wave turns 1024 consecutive weights of one row (4 coalesced 16-B-per-lane
+// loads for f32) into 256 packed bytes written by ONE coalesced dword-per-lane store.
+//   load i (0..3): lane l reads weights [4*(64 i + l), +4)  -> byte 64 i + l of the chunk
+//   quad_or gathers bytes 4q..4q+3 of load i into dword 16 i + q (held by the 4 lanes of quad q)
+//   lane l stores dword 16 (l & 3) + (l >> 2)
+// Requires k % 16 == 0, 16-byte aligned rows of w, 4-byte aligned rows of pw.
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) quantize_pack_fast_kernel(const T* __restrict__ w, int64_t n, int64_t k,
+                                                                 int64_t ld_w, float thr, uint8_t* __restrict__ pw,
+                                                                 int64_t ld_pw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t chunks_per_row = (k + 1023) / 1024;
+    const int64_t total = n * chunks_per_row;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t dwords_per_row = k / 16;
+    for (int64_t c = wave0; c < total; c += nwaves) {
+        const int64_t row = c / chunks_per_row;
+        const int64_t kc = (c - row * chunks_per_row) * 1024;  // first weight of the chunk
+        const T* src = w + row * ld_w + kc;
+        float v[4][4];
+        bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t e = (int64_t)(64 * i + lane) * 4;
+            ok[i] = (kc + e) < k;
+            if (ok[i]) load4<T>(src + e, v[i]);
+        }
+        uint32_t d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t b = 0;
+            if (ok[i]) {
+                b = quantize_code<MODE>(v[i][0], thr) | (quantize_code<MODE>(v[i][1], thr) << 2) |
+                    (quantize_code<MODE>(v[i][2], thr) << 4) | (quantize_code<MODE>(v[i][3], thr) << 6);
+            }
+            d[i] = quad_or(b << (8 * (lane & 3)));
+        }
+        const int sel = lane & 3;
+        const uint32_t mine = sel == 0 ? d[0] : sel == 1 ? d[1] : sel == 2 ? d[2] : d[3];
+        const int64_t dw = kc / 16 + 16 * sel + (lane >> 2);
+        if (dw < dwords_per_row) *reinterpret_cast<uint32_t*>(pw + row * ld_pw + dw * 4) = mine;
+    }
+}
+
+// Generic quantize+pack: one thread per packed byte, scalar loads, any k / alignment.
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) quantize_pack_generic_kernel(const T* __restrict__ w, int64_t n, int64_t k,
+                                                                    int64_t ld_w, float thr, uint8_t* __restrict__ pw,
+                                                                    int64_t ld_pw) {
+    const int64_t bytes_per_row = (k + 3) / 4;
+    const int64_t total = n * bytes_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / bytes_per_row, j = i - row * bytes_per_row;
+        uint32_t b = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t kk = 4 * j + e;
+            const uint32_t code = kk < k ? quantize_code<MODE>(to_float(w[row * ld_w + kk]), thr) : 1u;
+            b |= code << (2 * e);
+        }
+        pw[row * ld_pw + j] = (uint8_t)b;
+    }
+}
+
+__global__ void __launch_bounds__(256) pack_i8_kernel(const int8_t* __restrict__ t, int64_t n, int64_t k, int64_t ld_t,
+                                                      uint8_t* __restrict__ pw, int64_t ld_pw, int vec) {
+    const int64_t bytes_per_row = (k + 3) / 4;
+    const int64_t total = n * bytes_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / bytes_per_row, j = i - row * bytes_per_row;
+        uint32_t b;
+        if (vec && 4 * j + 3 < k) {
+            // four int8 in one dword: code = (value + 1) & 3 per byte; masking to two bits first
+            // keeps the per-byte add free of carries into the neighbouring byte
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(t + row * ld_t + 4 * j);
+            const uint32_t nc = ((v & 0x03030303u) + 0x01010101u) & 0x03030303u;
+            b = (nc & 0x3u) | ((nc >> 6) & 0xCu) | ((nc >> 12) & 0x30u) | ((nc >> 18) & 0xC0u);
+        } else {
+            b = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t kk = 4 * j + e;
+                const uint32_t code = kk < k ? ((uint32_t)(t[row * ld_t + kk] + 1) & 3u) : 1u;
+                b |= code << (2 * e);
+            }
+        }
+        pw[row * ld_pw + j] = (uint8_t)b;
+    }
+}
+
+template <typename T> __device__ __forceinline__ T value_as(int v) { return from_float<T>((float)v); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) unpack_kernel(const uint8_t* __restrict__ pw, int64_t n, int64_t k, int64_t ld_pw,
+                                                     T* __restrict__ out, int64_t ld_out, int vec) {
+    const int64_t bytes_per_row = (k + 3) / 4;
+    const int64_t total = n * bytes_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / bytes_per_row, j = i - row * bytes_per_row;
+        const uint32_t b = pw[row * ld_pw + j];
+        T v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = value_as<T>(code_value(b, e));
+        T* dst = out + row * ld_out + 4 * j;
+        if (vec && 4 * j + 3 < k) {
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(v);
+            } else if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(v);
+            } else {
+                *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(v);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * j + e < k) dst[e] = v[e];
+        }
+    }
+}
+
+// planar layouts: S = ceil(len/4); byte j holds elements j, S+j, 2S+j, 3S+j
+template <int FORMAT>
+__global__ void __launch_bounds__(256) pack_planar_kernel(const int8_t* __restrict__ t, int64_t len, uint8_t* __restrict__ pw) {
+    const int64_t s = (len + 3) / 4;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < s; j += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t b = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t idx = i * s + j;
+            const int v = idx < len ? (int)t[idx] : 0;
+            uint32_t code;
+            if constexpr (FORMAT == TVL_PLANAR_A) code = (uint32_t)(v == 1) ^ ((uint32_t)(v == -1) << 1);
+            else code = (uint32_t)(v + 1) & 0xFFu;  // the reference ORs the whole shifted byte (uint8 arithmetic)
+            b |= (code << (2 * i));
+        }
+        pw[j] = (uint8_t)b;
+    }
+}
+
+template <typename T, int FORMAT>
+__global__ void __launch_bounds__(256) unpack_planar_kernel(const uint8_t* __restrict__ pw, int64_t s, T* __restrict__ out) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < s; j += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = pw[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t c = (b >> (2 * i)) & 3u;
+            int v;
+            if constexpr (FORMAT == TVL_PLANAR_A) v = (int)(c & 1u) - (int)(c >> 1);
+            else v = (int)c - 1;
+            out[i * s + j] = value_as<T>(v);
+        }
+    }
+}
+
+template <typename TI, typename TO, int MODE>
+__global__ void __launch_bounds__(256) quantize_dense_kernel(const TI* __restrict__ w, int64_t numel, float thr, TO* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)quantize_code<MODE>(to_float(w[i]), thr) - 1;
+        out[i] = value_as<TO>(v);
+    }
+}
+
+__global__ void __launch_bounds__(256) zero_out_kernel(const int32_t* __restrict__ in, int64_t numel, int32_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (i == 0) ? in[0] : 0;
+}
+
+__global__ void __launch_bounds__(256) copy_u8_kernel(const uint8_t* __restrict__ in, int64_t numel, uint8_t* __restrict__ out) {
+    const int64_t nvec = numel / 16;
+    const bool vec = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        for (int64_t i = tid; i < nvec; i += nth)
+            reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(in)[i];
+        for (int64_t i = nvec * 16 + tid; i < numel; i += nth) out[i] = in[i];
+    } else {
+        for (int64_t i = tid; i < numel; i += nth) out[i] = in[i];
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+static inline int grid_for(int64_t work_items, int per_block) {
+    int64_t g = ceil_div(work_items, per_block);
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;  // 8 blocks per CU, grid-stride beyond
+    return (int)g;
+}
+
+template <typename T>
+static int launch_quantize_pack_t(const T* w, int64_t n, int64_t k, int64_t ld_w, int mode, float thr, uint8_t* pw,
+                                  int64_t ld_pw, hipStream_t st) {
+    const bool fast = (k % 16 == 0) && aligned(w, 4 * sizeof(T)) && (ld_w % 4 == 0) && aligned(pw, 4) && (ld_pw % 4 == 0);
+#define TVL_QP(MODE)                                                                                             \
+    if (fast) {                                                                                                  \
+        const int64_t chunks = n * ceil_div(k, 1024);                                                            \
+        hipLaunchKernelGGL((quantize_pack_fast_kernel<T, MODE>), dim3(grid_for(chunks, 4)), dim3(256), 0, st, w, n, k, ld_w, \
+                           thr, pw, ld_pw);                                                                      \
+    } else {                                                                                                     \
+        hipLaunchKernelGGL((quantize_pack_generic_kernel<T, MODE>), dim3(grid_for(n * ceil_div(k, 4), 256)), dim3(256), 0, st, \
+                           w, n, k, ld_w, thr, pw, ld_pw);                                                       \
+    }
+    switch (mode) {
+        case TVL_Q_TERNARY: TVL_QP(TVL_Q_TERNARY) break;
+        case TVL_Q_SIGN: TVL_QP(TVL_Q_SIGN) break;
+        case TVL_Q_STEP: TVL_QP(TVL_Q_STEP) break;
+        default: set_error("unknown quantizer mode %d", mode); return TVL_ERR_INVALID;
+    }
+#undef TVL_QP
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+int launch_quantize_pack(const void* w, int w_dtype, int64_t n, int64_t k, int64_t ld_w, int mode, float thr, uint8_t* pw,
+                         int64_t ld_pw, hipStream_t st) {
+    switch (w_dtype) {
+        case TVL_F32: return launch_quantize_pack_t((const float*)w, n, k, ld_w, mode, thr, pw, ld_pw, st);
+        case TVL_F16: return launch_quantize_pack_t((const f16*)w, n, k, ld_w, mode, thr, pw, ld_pw, st);
+        case TVL_BF16: return launch_quantize_pack_t((const bf16_t*)w, n, k, ld_w, mode, thr, pw, ld_pw, st);
+        default: set_error("quantize_pack: unsupported weight dtype %d", w_dtype); return TVL_ERR_INVALID;
+    }
+}
+
+int launch_pack_i8(const int8_t* t, int64_t n, int64_t k, int64_t ld_t, uint8_t* pw, int64_t ld_pw, hipStream_t st) {
+    const int vec = aligned(t, 4) && (ld_t % 4 == 0);
+    hipLaunchKernelGGL(pack_i8_kernel, dim3(grid_for(n * ceil_div(k, 4), 256)), dim3(256), 0, st, t, n, k, ld_t, pw, ld_pw, vec);
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+int launch_unpack(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, void* out, int out_dtype, int64_t ld_out,
+                  hipStream_t st) {
+    const dim3 grid(grid_for(n * ceil_div(k, 4), 256)), block(256);
+    const size_t es = dtype_size(out_dtype);
+    const int vec = aligned(out, 4 * es) && (ld_out % 4 == 0);
+    switch (out_dtype) {
+        case TVL_F32: hipLaunchKernelGGL(unpack_kernel<float>, grid, block, 0, st, pw, n, k, ld_pw, (float*)out, ld_out, vec); break;
+        case TVL_F16: hipLaunchKernelGGL(unpack_kernel<f16>, grid, block, 0, st, pw, n, k, ld_pw, (f16*)out, ld_out, vec); break;
+        case TVL_BF16: hipLaunchKernelGGL(unpack_kernel<bf16_t>, grid, block, 0, st, pw, n, k, ld_pw, (bf16_t*)out, ld_out, vec); break;
+        case TVL_I8: hipLaunchKernelGGL(unpack_kernel<int8_t>, grid, block, 0, st, pw, n, k, ld_pw, (int8_t*)out, ld_out, vec); break;
+        default: set_error("unpack: unsupported output dtype %d", out_dtype); return TVL_ERR_INVALID;
+    }
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+int launch_pack_planar(const int8_t* t, int64_t len, int format, uint8_t* pw, hipStream_t st) {
+    const dim3 grid(grid_for(ceil_div(len, 4), 256)), block(256);
+    if (format == TVL_PLANAR_A) hipLaunchKernelGGL(pack_planar_kernel<TVL_PLANAR_A>, grid, block, 0, st, t, len, pw);
+    else if (format == TVL_PLANAR_B) hipLaunchKernelGGL(pack_planar_kernel<TVL_PLANAR_B>, grid, block, 0, st, t, len, pw);
+    else { set_error("unknown planar format %d", format); return TVL_ERR_INVALID; }
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+template <int FORMAT>
+static int launch_unpack_planar_f(const uint8_t* pw, int64_t s, void* out, int out_dtype, hipStream_t st) {
+    const dim3 grid(grid_for(s, 256)), block(256);
+    switch (out_dtype) {
+        case TVL_F32: hipLaunchKernelGGL((unpack_planar_kernel<float, FORMAT>), grid, block, 0, st, pw, s, (float*)out); break;
+        case TVL_F16: hipLaunchKernelGGL((unpack_planar_kernel<f16, FORMAT>), grid, block, 0, st, pw, s, (f16*)out); break;
+        case TVL_BF16: hipLaunchKernelGGL((unpack_planar_kernel<bf16_t, FORMAT>), grid, block, 0, st, pw, s, (bf16_t*)out); break;
+        case TVL_I8: hipLaunchKernelGGL((unpack_planar_kernel<int8_t, FORMAT>), grid, block, 0, st, pw, s, (int8_t*)out); break;
+        default: set_error("unpack_planar: unsupported output dtype %d", out_dtype); return TVL_ERR_INVALID;
+    }
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+int launch_unpack_planar(const uint8_t* pw, int64_t s, int format, void* out, int out_dtype, hipStream_t st) {
+    if (format == TVL_PLANAR_A) return launch_unpack_planar_f<TVL_PLANAR_A>(pw, s, out, out_dtype, st);
+    if (format == TVL_PLANAR_B) return launch_unpack_planar_f<TVL_PLANAR_B>(pw, s, out, out_dtype, st);
+    set_error("unknown planar format %d", format);
+    return TVL_ERR_INVALID;
+}
+
+template <typename TI, typename TO>
+static int launch_quantize_dense_t(const TI* w, int64_t numel, int mode, float thr, TO* out, hipStream_t st) {
+    const dim3 grid(grid_for(numel, 256)), block(256);
+    switch (mode) {
+        case TVL_Q_TERNARY: hipLaunchKernelGGL((quantize_dense_kernel<TI, TO, TVL_Q_TERNARY>), grid, block, 0, st, w, numel, thr, out); break;
+        case TVL_Q_SIGN: hipLaunchKernelGGL((quantize_dense_kernel<TI, TO, TVL_Q_SIGN>), grid, block, 0, st, w, numel, thr, out); break;
+        case TVL_Q_STEP: hipLaunchKernelGGL((quantize_dense_kernel<TI, TO, TVL_Q_STEP>), grid, block, 0, st, w, numel, thr, out); break;
+        default: set_error("unknown quantizer mode %d", mode); return TVL_ERR_INVALID;
+    }
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+int launch_quantize_dense(const void* w, int w_dtype, int64_t numel, int mode, float thr, void* out, int out_dtype, hipStream_t st) {
+    if (out_dtype == TVL_I8) {
+        switch (w_dtype) {
+            case TVL_F32: return launch_quantize_dense_t((const float*)w, numel, mode, thr, (int8_t*)out, st);
+            case TVL_F16: return launch_quantize_dense_t((const f16*)w, numel, mode, thr, (int8_t*)out, st);
+            case TVL_BF16: return launch_quantize_dense_t((const bf16_t*)w, numel, mode, thr, (int8_t*)out, st);
+        }
+    } else if (out_dtype == w_dtype) {
+        switch (w_dtype) {
+            case TVL_F32: return launch_quantize_dense_t((const float*)w, numel, mode, thr, (float*)out, st);
+            case TVL_F16: return launch_quantize_dense_t((const f16*)w, numel, mode, thr, (f16*)out, st);
+            case TVL_BF16: return launch_quantize_dense_t((const bf16_t*)w, numel, mode, thr, (bf16_t*)out, st);
+        }
+    }
+    set_error("quantize: unsupported dtype combination in=%d out=%d (out must be the input type or int8)", w_dtype, out_dtype);
+    return TVL_ERR_INVALID;
+}
+
+int launch_zero_out(const int32_t* in, int64_t numel, int32_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(zero_out_kernel, dim3(grid_for(numel, 256)), dim3(256), 0, st, in, numel, out);
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+int launch_copy_u8(const uint8_t* in, int64_t numel, uint8_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(copy_u8_kernel, dim3(grid_for(ceil_div(numel, 16), 256)), dim3(256), 0, st, in, numel, out);
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+}  // namespace tvl

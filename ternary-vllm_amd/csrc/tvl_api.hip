@@ -1,0 +1,198 @@
+// C ABI of libternary_hip.so: argument validation and kernel selection.  See include/tvl.h.
+#include "tvl_common.h"
+#include "tvl_kernels.h"
+
+#include <string>
+
+namespace tvl {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+static inline bool float_dtype(int dt) { return dt == TVL_F32 || dt == TVL_F16 || dt == TVL_BF16; }
+
+}  // namespace tvl
+
+using namespace tvl;
+
+extern "C" {
+
+int tvl_version(void) { return TVL_VERSION; }
+
+const char* tvl_last_error(void) { return g_last_error.c_str(); }
+
+const char* tvl_build_info(void) {
+    return "libternary_hip: gfx950 (CDNA4) HIP kernels; packed ternary GEMM on v_mfma_f32_32x32x16_{f16,bf16}";
+}
+
+int tvl_quantize_pack(const void* w, int w_dtype, int64_t n, int64_t k, int64_t ld_w, int mode, float threshold, uint8_t* pw,
+                      int64_t ld_pw, void* stream) {
+    TVL_REQUIRE(n >= 0 && k >= 0, "quantize_pack: negative shape n=%lld k=%lld", (long long)n, (long long)k);
+    TVL_REQUIRE(float_dtype(w_dtype), "quantize_pack: weight dtype must be f32/f16/bf16, got %d", w_dtype);
+    TVL_REQUIRE(mode == TVL_Q_TERNARY || mode == TVL_Q_SIGN || mode == TVL_Q_STEP, "quantize_pack: unknown quantizer %d", mode);
+    if (ld_w == 0) ld_w = k;
+    if (ld_pw == 0) ld_pw = ceil_div(k, 4);
+    TVL_REQUIRE(ld_w >= k, "quantize_pack: ld_w=%lld < k=%lld", (long long)ld_w, (long long)k);
+    TVL_REQUIRE(ld_pw >= ceil_div(k, 4), "quantize_pack: ld_pw=%lld < ceil(k/4)=%lld", (long long)ld_pw, (long long)ceil_div(k, 4));
+    if (n == 0 || k == 0) return TVL_OK;
+    TVL_REQUIRE(w && pw, "quantize_pack: NULL pointer");
+    TVL_REQUIRE(aligned(w, dtype_size(w_dtype)), "quantize_pack: misaligned weight pointer");
+    return launch_quantize_pack(w, w_dtype, n, k, ld_w, mode, threshold, pw, ld_pw, (hipStream_t)stream);
+}
+
+int tvl_pack_i8(const int8_t* t, int64_t n, int64_t k, int64_t ld_t, uint8_t* pw, int64_t ld_pw, void* stream) {
+    TVL_REQUIRE(n >= 0 && k >= 0, "pack: negative shape");
+    if (ld_t == 0) ld_t = k;
+    if (ld_pw == 0) ld_pw = ceil_div(k, 4);
+    TVL_REQUIRE(ld_t >= k && ld_pw >= ceil_div(k, 4), "pack: leading dimension too small");
+    if (n == 0 || k == 0) return TVL_OK;
+    TVL_REQUIRE(t && pw, "pack: NULL pointer");
+    return launch_pack_i8(t, n, k, ld_t, pw, ld_pw, (hipStream_t)stream);
+}
+
+int tvl_unpack(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, void* out, int out_dtype, int64_t ld_out, void* stream) {
+    TVL_REQUIRE(n >= 0 && k >= 0, "unpack: negative shape");
+    TVL_REQUIRE(float_dtype(out_dtype) || out_dtype == TVL_I8, "unpack: output dtype must be f32/f16/bf16/i8, got %d", out_dtype);
+    if (ld_pw == 0) ld_pw = ceil_div(k, 4);
+    if (ld_out == 0) ld_out = k;
+    TVL_REQUIRE(ld_pw >= ceil_div(k, 4), "unpack: orig_dim=%lld needs %lld packed bytes per row, rows have %lld", (long long)k,
+                (long long)ceil_div(k, 4), (long long)ld_pw);
+    TVL_REQUIRE(ld_out >= k, "unpack: ld_out too small");
+    if (n == 0 || k == 0) return TVL_OK;
+    TVL_REQUIRE(pw && out, "unpack: NULL pointer");
+    TVL_REQUIRE(aligned(out, dtype_size(out_dtype)), "unpack: misaligned output pointer");
+    return launch_unpack(pw, n, k, ld_pw, out, out_dtype, ld_out, (hipStream_t)stream);
+}
+
+int tvl_pack_planar_i8(const int8_t* t, int64_t len, int format, uint8_t* pw, void* stream) {
+    TVL_REQUIRE(len >= 0, "pack_planar: negative length");
+    TVL_REQUIRE(format == TVL_PLANAR_A || format == TVL_PLANAR_B, "pack_planar: unknown format %d", format);
+    if (len == 0) return TVL_OK;
+    TVL_REQUIRE(t && pw, "pack_planar: NULL pointer");
+    return launch_pack_planar(t, len, format, pw, (hipStream_t)stream);
+}
+
+int tvl_unpack_planar(const uint8_t* pw, int64_t packed_len, int format, void* out, int out_dtype, void* stream) {
+    TVL_REQUIRE(packed_len >= 0, "unpack_planar: negative length");
+    TVL_REQUIRE(format == TVL_PLANAR_A || format == TVL_PLANAR_B, "unpack_planar: unknown format %d", format);
+    TVL_REQUIRE(float_dtype(out_dtype) || out_dtype == TVL_I8, "unpack_planar: output dtype must be f32/f16/bf16/i8");
+    if (packed_len == 0) return TVL_OK;
+    TVL_REQUIRE(pw && out, "unpack_planar: NULL pointer");
+    return launch_unpack_planar(pw, packed_len, format, out, out_dtype, (hipStream_t)stream);
+}
+
+int tvl_quantize(const void* w, int w_dtype, int64_t numel, int mode, float threshold, void* out, int out_dtype, void* stream) {
+    TVL_REQUIRE(numel >= 0, "quantize: negative size");
+    TVL_REQUIRE(float_dtype(w_dtype), "quantize: input dtype must be f32/f16/bf16");
+    TVL_REQUIRE(mode == TVL_Q_TERNARY || mode == TVL_Q_SIGN || mode == TVL_Q_STEP, "quantize: unknown quantizer %d", mode);
+    if (numel == 0) return TVL_OK;
+    TVL_REQUIRE(w && out, "quantize: NULL pointer");
+    return launch_quantize_dense(w, w_dtype, numel, mode, threshold, out, out_dtype, (hipStream_t)stream);
+}
+
+size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+    (void)m; (void)n; (void)k;
+    return 0;  // no kernel of this version needs scratch memory
+}
+
+int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                       const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
+    TVL_REQUIRE(m >= 0 && n >= 0 && k >= 0, "ternary_matmul: negative shape m=%lld n=%lld k=%lld", (long long)m, (long long)n, (long long)k);
+    TVL_REQUIRE(float_dtype(x_dtype), "ternary_matmul: activation dtype must be f32/f16/bf16, got %d", x_dtype);
+    TVL_REQUIRE(float_dtype(y_dtype), "ternary_matmul: output dtype must be f32/f16/bf16, got %d", y_dtype);
+    TVL_REQUIRE(act == TVL_ACT_NONE || act == TVL_ACT_GELU_TANH, "ternary_matmul: unknown activation %d", act);
+    if (ld_x == 0) ld_x = k;
+    if (ld_pw == 0) ld_pw = ceil_div(k, 4);
+    if (ld_y == 0) ld_y = n;
+    TVL_REQUIRE(ld_x >= k, "ternary_matmul: ld_x=%lld < k=%lld", (long long)ld_x, (long long)k);
+    TVL_REQUIRE(ld_pw >= ceil_div(k, 4),
+                "ternary_matmul: packed rows hold %lld bytes but k=%lld needs %lld (x and pw disagree on the input dimension)",
+                (long long)ld_pw, (long long)k, (long long)ceil_div(k, 4));
+    TVL_REQUIRE(ld_y >= n, "ternary_matmul: ld_y=%lld < n=%lld", (long long)ld_y, (long long)n);
+    TVL_REQUIRE(!(clip != clip), "ternary_matmul: clip is NaN");
+    if (m == 0 || n == 0) return TVL_OK;
+    TVL_REQUIRE(y && scale, "ternary_matmul: NULL output or scale pointer");
+    TVL_REQUIRE(k == 0 || (x && pw), "ternary_matmul: NULL input pointer");
+    TVL_REQUIRE(aligned(x, dtype_size(x_dtype)) && aligned(y, dtype_size(y_dtype)) && aligned(scale, 4) && aligned(bias, 4),
+                "ternary_matmul: misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (gemm_mfma_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
+        return launch_gemm_mfma(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
+    return launch_gemm_generic(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
+}
+
+int tvl_ternary_mm_f32(const float* x, int64_t m, int64_t k, int64_t ld_x, const float* tm, int64_t n, int64_t ld_tm, float* res,
+                       int64_t ld_res, void* stream) {
+    TVL_REQUIRE(m >= 0 && n >= 0 && k >= 0, "ternary_mm: negative shape");
+    if (ld_x == 0) ld_x = k;
+    if (ld_tm == 0) ld_tm = k;
+    if (ld_res == 0) ld_res = n;
+    TVL_REQUIRE(ld_x >= k && ld_tm >= k && ld_res >= n, "ternary_mm: leading dimension too small");
+    if (m == 0 || n == 0) return TVL_OK;
+    TVL_REQUIRE(res && (k == 0 || (x && tm)), "ternary_mm: NULL pointer");
+    return launch_ternary_mm(x, m, k, ld_x, tm, n, ld_tm, res, ld_res, (hipStream_t)stream);
+}
+
+size_t tvl_fit_scale_workspace_bytes(int64_t n, int64_t k) {
+    (void)n; (void)k;
+    return fit_workspace_bytes();
+}
+
+int tvl_fit_ternary_scale_f32(const float* w, int64_t n, int64_t k, int64_t ld_w, int uniform, int iters, float* scale, float* latent,
+                              int64_t ld_latent, void* workspace, size_t workspace_bytes, void* stream) {
+    TVL_REQUIRE(n > 0 && k > 0, "fit_ternary_scale: empty matrix");
+    TVL_REQUIRE(iters >= 0, "fit_ternary_scale: negative iteration count");
+    if (ld_w == 0) ld_w = k;
+    if (ld_latent == 0) ld_latent = k;
+    TVL_REQUIRE(ld_w >= k && ld_latent >= k, "fit_ternary_scale: leading dimension too small");
+    TVL_REQUIRE(w && scale, "fit_ternary_scale: NULL pointer");
+    TVL_REQUIRE(n <= INT32_MAX, "fit_ternary_scale: too many rows");
+    if (uniform) {
+        TVL_REQUIRE(workspace && workspace_bytes >= fit_workspace_bytes() && aligned(workspace, 8),
+                    "fit_ternary_scale: the whole-matrix fit needs %zu bytes of 8-byte aligned workspace", fit_workspace_bytes());
+    }
+    return launch_fit_ternary(w, n, k, ld_w, uniform, iters, scale, latent, ld_latent, workspace, (hipStream_t)stream);
+}
+
+int tvl_fit_binary_scale_f32(const float* w, int64_t n, int64_t k, int64_t ld_w, int mode, int uniform, float prescale, int natural,
+                             float* scale, float* latent, int64_t ld_latent, void* workspace, size_t workspace_bytes, void* stream) {
+    TVL_REQUIRE(n > 0 && k > 0, "fit_binary_scale: empty matrix");
+    TVL_REQUIRE(mode == TVL_Q_SIGN || mode == TVL_Q_STEP, "fit_binary_scale: mode must be TVL_Q_SIGN or TVL_Q_STEP");
+    if (ld_w == 0) ld_w = k;
+    if (ld_latent == 0) ld_latent = k;
+    TVL_REQUIRE(ld_w >= k && ld_latent >= k, "fit_binary_scale: leading dimension too small");
+    TVL_REQUIRE(w && scale, "fit_binary_scale: NULL pointer");
+    TVL_REQUIRE(n <= INT32_MAX, "fit_binary_scale: too many rows");
+    if (uniform) {
+        TVL_REQUIRE(workspace && workspace_bytes >= fit_workspace_bytes() && aligned(workspace, 8),
+                    "fit_binary_scale: the whole-matrix fit needs %zu bytes of 8-byte aligned workspace", fit_workspace_bytes());
+    }
+    return launch_fit_binary(w, n, k, ld_w, mode, uniform, prescale, natural, scale, latent, ld_latent, workspace, (hipStream_t)stream);
+}
+
+int tvl_zero_out_i32(const int32_t* in, int64_t numel, int32_t* out, void* stream) {
+    TVL_REQUIRE(numel >= 0, "zero_out: negative size");
+    if (numel == 0) return TVL_OK;
+    TVL_REQUIRE(in && out, "zero_out: NULL pointer");
+    return launch_zero_out(in, numel, out, (hipStream_t)stream);
+}
+
+int tvl_prevent_folding_u8(const uint8_t* constant, int64_t numel, const void* witness, uint8_t* out, void* stream) {
+    (void)witness;
+    TVL_REQUIRE(numel >= 0, "prevent_folding: negative size");
+    if (numel == 0) return TVL_OK;
+    TVL_REQUIRE(constant && out, "prevent_folding: NULL pointer");
+    return launch_copy_u8(constant, numel, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// Shared helpers of libternary_hip.so: error reporting, dtype conversion, 2-bit code decode.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/tvl.h"
+
+namespace tvl {
+
+// ---- host-side error state (thread local) --------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define TVL_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::tvl::set_error(__VA_ARGS__);     \
+            return TVL_ERR_INVALID;            \
+        }                                      \
+    } while (0)
+
+#define TVL_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            ::tvl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return TVL_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+// after a kernel launch
+#define TVL_LAUNCH_CHECK() TVL_HIP_CHECK(hipGetLastError())
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+static inline size_t dtype_size(int dt) {
+    switch (dt) {
+        case TVL_F32: return 4;
+        case TVL_F16: return 2;
+        case TVL_BF16: return 2;
+        case TVL_I8: return 1;
+        case TVL_I32: return 4;
+        default: return 0;
+    }
+}
+
+// ---- device-side scalar conversion ---------------------------------------------------------
+using f16 = _Float16;
+struct bf16_t { uint16_t v; };
+
+__device__ __forceinline__ float to_float(float x) { return x; }
+__device__ __forceinline__ float to_float(f16 x) { return (float)x; }
+__device__ __forceinline__ float to_float(bf16_t x) { return __uint_as_float(((uint32_t)x.v) << 16); }
+
+template <typename T> __device__ __forceinline__ T from_float(float x);
+template <> __device__ __forceinline__ float from_float<float>(float x) { return x; }
+template <> __device__ __forceinline__ f16 from_float<f16>(float x) { return (f16)x; }  // round to nearest even
+template <> __device__ __forceinline__ bf16_t from_float<bf16_t>(float x) {
+    // round to nearest even, NaN stays NaN (the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+    __hip_bfloat16 h = __float2bfloat16(x);
+    bf16_t r;
+    r.v = *reinterpret_cast<uint16_t*>(&h);
+    return r;
+}
+template <> __device__ __forceinline__ int8_t from_float<int8_t>(float x) { return (int8_t)x; }
+
+// value of a 2-bit code: code - 1  (0 -> -1, 1 -> 0, 2 -> +1, 3 -> +2)
+__device__ __forceinline__ int code_value(uint32_t byte, int i) { return (int)((byte >> (2 * i)) & 3u) - 1; }
+
+// quantizers on a float value -> 2-bit code (value + 1)
+template <int MODE> __device__ __forceinline__ uint32_t quantize_code(float w, float thr) {
+    if constexpr (MODE == TVL_Q_TERNARY) {
+        // (w >= thr) - (w <= -thr) + 1 ; NaN compares false twice -> code 1 (value 0)
+        return 1u + (uint32_t)(w >= thr) - (uint32_t)(w <= -thr);
+    } else if constexpr (MODE == TVL_Q_SIGN) {
+        return (w >= 0.0f) ? 2u : 0u;  // +1 / -1
+    } else {
+        return (w >= 0.0f) ? 2u : 1u;  // +1 / 0
+    }
+}
+
+// epilogue shared by every matmul kernel: two roundings (multiply, then add), clip, activation
+__device__ __forceinline__ float gelu_tanh_f32(float x) {
+    const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
+    const float k1 = 0.044715f;
+    float inner = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+template <bool HAS_BIAS, int ACT>
+__device__ __forceinline__ float epilogue(float acc, float scale, float bias, float clip) {
+    // the reference does `x *= scale; x += bias` as two float32 operations: keep the compiler from
+    // contracting them into one fma (the build uses -ffp-contract=fast elsewhere)
+#pragma clang fp contract(off)
+    float y = acc * scale;
+    if constexpr (HAS_BIAS) y = y + bias;
+    y = (y < -clip) ? -clip : ((y > clip) ? clip : y);  // NaN stays NaN, like torch.clip
+    if constexpr (ACT == TVL_ACT_GELU_TANH) y = gelu_tanh_f32(y);
+    return y;
+}
+
+}  // namespace tvl

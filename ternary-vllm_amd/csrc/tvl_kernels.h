@@ -1,0 +1,42 @@
+// Internal launcher interface between the C ABI (tvl_api.hip) and the kernel files.
+// Arguments were validated by the caller; every launcher returns a TVL_* status.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace tvl {
+
+// pack_kernels.hip
+int launch_quantize_pack(const void* w, int w_dtype, int64_t n, int64_t k, int64_t ld_w, int mode, float thr, uint8_t* pw,
+                         int64_t ld_pw, hipStream_t st);
+int launch_pack_i8(const int8_t* t, int64_t n, int64_t k, int64_t ld_t, uint8_t* pw, int64_t ld_pw, hipStream_t st);
+int launch_unpack(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, void* out, int out_dtype, int64_t ld_out, hipStream_t st);
+int launch_pack_planar(const int8_t* t, int64_t len, int format, uint8_t* pw, hipStream_t st);
+int launch_unpack_planar(const uint8_t* pw, int64_t s, int format, void* out, int out_dtype, hipStream_t st);
+int launch_quantize_dense(const void* w, int w_dtype, int64_t numel, int mode, float thr, void* out, int out_dtype, hipStream_t st);
+int launch_zero_out(const int32_t* in, int64_t numel, int32_t* out, hipStream_t st);
+int launch_copy_u8(const uint8_t* in, int64_t numel, uint8_t* out, hipStream_t st);
+
+// gemm_generic.hip
+int launch_gemm_generic(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
+                        int64_t ld_pw, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype,
+                        int64_t ld_y, hipStream_t st);
+int launch_ternary_mm(const float* x, int64_t m, int64_t k, int64_t ld_x, const float* tm, int64_t n, int64_t ld_tm, float* res,
+                      int64_t ld_res, hipStream_t st);
+
+// gemm_mfma.hip
+bool gemm_mfma_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
+                         int64_t ld_pw);
+int launch_gemm_mfma(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
+                     int64_t ld_pw, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype,
+                     int64_t ld_y, hipStream_t st);
+
+// fit_scale.hip
+size_t fit_workspace_bytes();
+int launch_fit_ternary(const float* w, int64_t n, int64_t k, int64_t ld_w, int uniform, int iters, float* scale, float* latent,
+                       int64_t ld_latent, void* workspace, hipStream_t st);
+int launch_fit_binary(const float* w, int64_t n, int64_t k, int64_t ld_w, int mode, int uniform, float prescale, int natural,
+                      float* scale, float* latent, int64_t ld_latent, void* workspace, hipStream_t st);
+
+}  // namespace tvl

@@ -1,0 +1,418 @@
+"""Operator surface of the ternary / binary quantized-matmul path, backed by libternary_hip.so.
+
+Mirror of the reference's op-library loader: ``custom_ops_mod.py:27-30`` loads ``custom_ops.so``
+from the directory of the loader module and exposes snake_case callables (``zero_out``,
+``prevent_folding``); the packed ops ``pack_fn`` / ``unpack_ternary`` / ``ternary_matmul`` are
+what the reference imports from its larq_compute_engine fork
+(``impl/tf/moondream/ternary.py:22,281,334``, ``utils/conversion.py:72``).  Same names, same
+positional argument order.  TensorFlow is not part of this stack: tensors are torch tensors
+that live on an AMD GPU, and every op runs a hand-written HIP kernel through the C ABI
+declared in ``include/tvl.h`` - there is no CPU or PyTorch fallback; a missing library or a
+CPU tensor is an error.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, "libternary_hip.so")
+
+# enums of include/tvl.h
+F32, F16, BF16, I8, I32 = 0, 1, 2, 3, 4
+Q_TERNARY, Q_SIGN, Q_STEP = 0, 1, 2
+ACT_NONE, ACT_GELU_TANH = 0, 1
+PLANAR_A, PLANAR_B = 0, 1
+ERR_INVALID, ERR_HIP = 1, 2
+
+_DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16, torch.int8: I8, torch.int32: I32}
+_QUANT = {"ternary": Q_TERNARY, "binary": Q_SIGN, "sign": Q_SIGN, "binary01": Q_STEP, "step": Q_STEP}
+
+_c_i64, _c_int, _c_f32, _c_vp, _c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); also the list of symbols the library must export
+SIGNATURES = {
+    "tvl_version": (_c_int, []),
+    "tvl_last_error": (ctypes.c_char_p, []),
+    "tvl_build_info": (ctypes.c_char_p, []),
+    "tvl_quantize_pack": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_int, _c_f32, _c_vp, _c_i64, _c_vp]),
+    "tvl_pack_i8": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_vp]),
+    "tvl_unpack": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_int, _c_i64, _c_vp]),
+    "tvl_pack_planar_i8": (_c_int, [_c_vp, _c_i64, _c_int, _c_vp, _c_vp]),
+    "tvl_unpack_planar": (_c_int, [_c_vp, _c_i64, _c_int, _c_vp, _c_int, _c_vp]),
+    "tvl_quantize": (_c_int, [_c_vp, _c_int, _c_i64, _c_int, _c_f32, _c_vp, _c_int, _c_vp]),
+    "tvl_ternary_matmul": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_f32,
+                                    _c_int, _c_vp, _c_int, _c_i64, _c_vp, _c_sz, _c_vp]),
+    "tvl_ternary_matmul_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "tvl_ternary_mm_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_i64, _c_vp]),
+    "tvl_fit_ternary_scale_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_i64, _c_vp,
+                                           _c_sz, _c_vp]),
+    "tvl_fit_binary_scale_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_f32, _c_int, _c_vp, _c_vp,
+                                          _c_i64, _c_vp, _c_sz, _c_vp]),
+    "tvl_fit_scale_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
+    "tvl_zero_out_i32": (_c_int, [_c_vp, _c_i64, _c_vp, _c_vp]),
+    "tvl_prevent_folding_u8": (_c_int, [_c_vp, _c_i64, _c_vp, _c_vp, _c_vp]),
+}
+
+
+def _load_library() -> ctypes.CDLL:
+    if not os.path.exists(LIBRARY_PATH):
+        raise ImportError(
+            f"{LIBRARY_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback implementation.")
+    lib = ctypes.CDLL(LIBRARY_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = _load_library()
+
+
+def library_version() -> int:
+    return int(_lib.tvl_version())
+
+
+def build_info() -> str:
+    return _lib.tvl_build_info().decode()
+
+
+def _check(status: int) -> None:
+    if status == 0:
+        return
+    msg = _lib.tvl_last_error().decode(errors="replace")
+    if status == ERR_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def _gpu(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: tensor must live on the GPU (got device {t.device}); this op has no CPU path")
+    return t
+
+
+def _stream(t: torch.Tensor) -> int:
+    return int(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dt(t: torch.Tensor, name: str) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise ValueError(f"{name}: unsupported dtype {t.dtype}") from None
+
+
+def _rows(t: torch.Tensor, name: str) -> torch.Tensor:
+    """2-D view with unit stride in the last dimension (row stride passed as ld)."""
+    if t.dim() != 2:
+        raise ValueError(f"{name}: expected a 2-D tensor, got shape {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return int(t.stride(0)) if t.shape[0] > 1 else int(max(t.shape[1], 1))
+
+
+# --------------------------------------------------------------------------------------------
+# plumbing ops (custom_ops_mod.py:29-30)
+# --------------------------------------------------------------------------------------------
+
+def zero_out(x) -> torch.Tensor:
+    """Keep the first (flat) element, zero the rest.  ``custom_ops_mod.py:29``; int32 like the
+    reference op's tests (``zero_out_tests.py:9``).  Accepts a tensor or a nested list."""
+    if not isinstance(x, torch.Tensor):
+        x = torch.tensor(x, dtype=torch.int32, device="cuda")
+    x = _gpu(x, "zero_out")
+    if x.dtype != torch.int32:
+        raise ValueError(f"zero_out: expected int32, got {x.dtype}")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(_lib.tvl_zero_out_i32(x.data_ptr(), x.numel(), out.data_ptr(), _stream(x)))
+    return out
+
+
+def prevent_folding(constant: torch.Tensor, witness: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Identity on a uint8 ``constant``; ``witness`` is only a fake data dependency
+    (``custom_ops_mod.py:30``, Python twin ``impl/tf/moondream/ternary.py:28-30``)."""
+    constant = _gpu(constant, "prevent_folding")
+    if constant.dtype != torch.uint8:
+        raise ValueError(f"prevent_folding: expected uint8, got {constant.dtype}")
+    constant = constant.contiguous()
+    out = torch.empty_like(constant)
+    wptr = witness.data_ptr() if isinstance(witness, torch.Tensor) and witness.is_cuda else None
+    with torch.cuda.device(constant.device):
+        _check(_lib.tvl_prevent_folding_u8(constant.data_ptr(), constant.numel(), wptr, out.data_ptr(), _stream(constant)))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# pack / unpack
+# --------------------------------------------------------------------------------------------
+
+def packed_row_bytes(k: int) -> int:
+    return (int(k) + 3) // 4
+
+
+def reference_row_bytes(k: int) -> int:
+    """Row length the reference allocates for ``pw`` (``impl/tf/moondream/ternary.py:269-270``)."""
+    r = int(k) % 4
+    return int(k) // 4 + ((4 - r) if r else 0)
+
+
+def pack_fn(t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int8 ``[N, K]`` in {-1,0,+1} -> uint8 ``[N, ceil(K/4)]`` (row-interleaved, code = value+1).
+    ``ops.pack_fn`` at ``utils/conversion.py:72``; layout of ``impl/tf/moondream/ternary.py:374-398``."""
+    t = _gpu(t, "pack_fn")
+    if t.dtype != torch.int8:
+        raise ValueError(f"pack_fn: expected int8 values in {{-1,0,1}}, got {t.dtype}")
+    t = _rows(t, "pack_fn")
+    n, k = t.shape
+    if out is None:
+        out = torch.empty((n, packed_row_bytes(k)), dtype=torch.uint8, device=t.device)
+    out = _check_pw(out, n, k, "pack_fn(out)")
+    with torch.cuda.device(t.device):
+        _check(_lib.tvl_pack_i8(t.data_ptr(), n, k, _ld(t), out.data_ptr(), _ld(out), _stream(t)))
+    return out
+
+
+def _check_pw(pw: torch.Tensor, n: Optional[int], k: int, name: str) -> torch.Tensor:
+    pw = _gpu(pw, name)
+    if pw.dtype != torch.uint8 or pw.dim() != 2:
+        raise ValueError(f"{name}: packed weights must be a 2-D uint8 tensor, got {pw.dtype} {tuple(pw.shape)}")
+    if pw.shape[1] > 1 and pw.stride(1) != 1:
+        raise ValueError(f"{name}: packed weights must have unit stride in the last dimension")
+    if n is not None and pw.shape[0] != n:
+        raise ValueError(f"{name}: packed weights have {pw.shape[0]} rows, expected {n}")
+    if pw.shape[1] < packed_row_bytes(k):
+        raise ValueError(f"{name}: packed rows hold {pw.shape[1]} bytes but orig_dim={k} needs {packed_row_bytes(k)}")
+    return pw
+
+
+def unpack_ternary(pw: torch.Tensor, orig_dim: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """uint8 ``[N, >=ceil(K/4)]`` -> ``[N, orig_dim]`` holding {-1,0,+1} (code 3 -> +2).
+    ``ops.unpack_ternary(pw, orig_dim)`` at ``impl/tf/moondream/ternary.py:334``."""
+    orig_dim = int(orig_dim)
+    if orig_dim < 0:
+        raise ValueError("unpack_ternary: orig_dim must be >= 0")
+    pw = _check_pw(pw, None, orig_dim, "unpack_ternary")
+    n = pw.shape[0]
+    out = torch.empty((n, orig_dim), dtype=dtype, device=pw.device)
+    with torch.cuda.device(pw.device):
+        _check(_lib.tvl_unpack(pw.data_ptr(), n, orig_dim, _ld(pw), out.data_ptr(), _dt(out, "unpack_ternary"), _ld(out),
+                               _stream(pw)))
+    return out
+
+
+def ternarize_pack(w: torch.Tensor, threshold: float = 0.5, quantization: str = "ternary",
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Latent weights ``[N, K]`` (f32/f16/bf16) -> packed uint8 ``[N, ceil(K/4)]`` in one pass:
+    quantize (``binary/modules.py:21-26`` ternary, ``:5-10`` sign, ``:13-18`` step) and pack.
+    Fuses ``ternary_act(w) -> int8 -> ops.pack_fn`` of ``utils/conversion.py:71-72``."""
+    w = _gpu(w, "ternarize_pack")
+    if quantization not in _QUANT:
+        raise ValueError(f"Unknown quantization: {quantization}")
+    w = _rows(w.detach(), "ternarize_pack")
+    n, k = w.shape
+    if out is None:
+        out = torch.empty((n, packed_row_bytes(k)), dtype=torch.uint8, device=w.device)
+    out = _check_pw(out, n, k, "ternarize_pack(out)")
+    with torch.cuda.device(w.device):
+        _check(_lib.tvl_quantize_pack(w.data_ptr(), _dt(w, "ternarize_pack"), n, k, _ld(w), _QUANT[quantization],
+                                      float(threshold), out.data_ptr(), _ld(out), _stream(w)))
+    return out
+
+
+def quantize(w: torch.Tensor, quantization: str = "ternary", threshold: float = 0.5,
+             dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Dense quantizer value: {-1,0,+1} / {-1,+1} / {0,1} in w's dtype (or int8)."""
+    w = _gpu(w, "quantize")
+    if quantization not in _QUANT:
+        raise ValueError(f"Unknown quantization: {quantization}")
+    w = w.detach().contiguous()
+    out = torch.empty(w.shape, dtype=dtype or w.dtype, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(_lib.tvl_quantize(w.data_ptr(), _dt(w, "quantize"), w.numel(), _QUANT[quantization], float(threshold),
+                                 out.data_ptr(), _dt(out, "quantize"), _stream(w)))
+    return out
+
+
+def pack_ternary_planar(t: torch.Tensor, fmt: str = "b") -> torch.Tensor:
+    """Planar 1-D layouts of the pure-TF layer: ``pack_ternary`` (fmt "a",
+    ``impl/tf/moondream/ternary.py:57-78``) and ``pack_ternary2`` (fmt "b", ``:114-133``)."""
+    t = _gpu(t, "pack_ternary_planar")
+    if t.dtype != torch.int8:
+        raise ValueError(f"pack_ternary_planar: expected int8, got {t.dtype}")
+    t = t.contiguous().reshape(-1)
+    out = torch.empty(((t.numel() + 3) // 4,), dtype=torch.uint8, device=t.device)
+    with torch.cuda.device(t.device):
+        _check(_lib.tvl_pack_planar_i8(t.data_ptr(), t.numel(), _planar(fmt), out.data_ptr(), _stream(t)))
+    return out
+
+
+def unpack_ternary_planar(pw: torch.Tensor, fmt: str = "b", dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Inverse of :func:`pack_ternary_planar`: ``4 * len(pw)`` values (the caller slices).
+    ``unpack_ternary_iterative`` / ``unpack_ternary_iterative2`` (``ternary.py:101-110``, ``:136-156``)."""
+    pw = _gpu(pw, "unpack_ternary_planar")
+    if pw.dtype != torch.uint8:
+        raise ValueError(f"unpack_ternary_planar: expected uint8, got {pw.dtype}")
+    pw = pw.contiguous().reshape(-1)
+    out = torch.empty((pw.numel() * 4,), dtype=dtype, device=pw.device)
+    with torch.cuda.device(pw.device):
+        _check(_lib.tvl_unpack_planar(pw.data_ptr(), pw.numel(), _planar(fmt), out.data_ptr(), _dt(out, "unpack_ternary_planar"),
+                                      _stream(pw)))
+    return out
+
+
+def _planar(fmt: str) -> int:
+    try:
+        return {"a": PLANAR_A, "b": PLANAR_B}[str(fmt).lower()]
+    except KeyError:
+        raise ValueError(f"Unknown planar format: {fmt}") from None
+
+
+# --------------------------------------------------------------------------------------------
+# the fused op
+# --------------------------------------------------------------------------------------------
+
+_ACTS = {None: ACT_NONE, "none": ACT_NONE, "gelu_tanh": ACT_GELU_TANH, "gelu": ACT_GELU_TANH}
+
+
+def ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias: Optional[torch.Tensor], clip_val: float,
+                   activation: Optional[str] = None, out_dtype: Optional[torch.dtype] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(clip((x @ unpack(pw)^T) * scale + bias, +-clip_val))``.
+
+    ``ops.ternary_matmul(x, pw, scale, bias, clip)`` at ``impl/tf/moondream/ternary.py:281``; the
+    order of operations is ``binary/modules.py:104-108``.  ``x``: ``[..., K]`` f16 / bf16 / f32;
+    ``pw``: uint8 ``[N, >= ceil(K/4)]``; ``scale``, ``bias``: ``[N]``.  The optional activation
+    (the reference applies it after the op, ``ternary.py:298-299``) is fused into the kernel.
+    """
+    x = _gpu(x, "ternary_matmul(x)")
+    if activation not in _ACTS:
+        raise ValueError(f"Unknown activation: {activation}")
+    if x.dim() < 1:
+        raise ValueError("ternary_matmul: x must have at least one dimension")
+    k = x.shape[-1]
+    pw = _check_pw(pw, None, k, "ternary_matmul(pw)")
+    n = pw.shape[0]
+    lead = x.shape[:-1]
+    x2 = _rows(x.reshape(-1, k), "ternary_matmul(x)")
+    m = x2.shape[0]
+    scale = _vec(scale, n, x.device, "scale")
+    bias = _vec(bias, n, x.device, "bias") if bias is not None else None
+    ydt = out_dtype or x.dtype
+    if out is None:
+        y = torch.empty((m, n), dtype=ydt, device=x.device)
+    else:
+        y = _rows(_gpu(out, "ternary_matmul(out)").reshape(-1, n), "ternary_matmul(out)")
+        if y.shape[0] != m or y.data_ptr() != out.data_ptr():
+            raise ValueError("ternary_matmul: `out` must be a contiguous [..., N] tensor matching x")
+    with torch.cuda.device(x.device):
+        _check(_lib.tvl_ternary_matmul(x2.data_ptr(), _dt(x2, "ternary_matmul(x)"), m, k, _ld(x2), pw.data_ptr(), n, _ld(pw),
+                                       scale.data_ptr(), bias.data_ptr() if bias is not None else None, float(clip_val),
+                                       _ACTS[activation], y.data_ptr(), _dt(y, "ternary_matmul(out)"), _ld(y), None, 0,
+                                       _stream(x)))
+    return y.reshape(*lead, n) if out is None else out
+
+
+def _vec(v: torch.Tensor, n: int, device, name: str) -> torch.Tensor:
+    v = _gpu(v, f"ternary_matmul({name})")
+    if v.device != device:
+        raise ValueError(f"ternary_matmul: {name} is on {v.device}, x on {device}")
+    if v.numel() != n:
+        raise ValueError(f"ternary_matmul: {name} has {v.numel()} elements, expected {n}")
+    v = v.detach().reshape(-1)
+    if v.dtype != torch.float32 or not v.is_contiguous():
+        v = v.float().contiguous()
+    return v
+
+
+def ternary_mm(m: torch.Tensor, tm: torch.Tensor) -> torch.Tensor:
+    """Multiplication-free select-and-sum with dense weights: ``m @ sign(tm)^T``
+    (``matrix_mul_tests.py:29-37``; float32)."""
+    m = _rows(_gpu(m, "ternary_mm(m)"), "ternary_mm(m)")
+    tm = _rows(_gpu(tm, "ternary_mm(tm)"), "ternary_mm(tm)")
+    if m.dtype != torch.float32 or tm.dtype != torch.float32:
+        raise ValueError("ternary_mm: float32 only")
+    if m.shape[1] != tm.shape[1]:
+        raise ValueError(f"ternary_mm: inner dimensions differ ({m.shape[1]} vs {tm.shape[1]})")
+    res = torch.empty((m.shape[0], tm.shape[0]), dtype=torch.float32, device=m.device)
+    with torch.cuda.device(m.device):
+        _check(_lib.tvl_ternary_mm_f32(m.data_ptr(), m.shape[0], m.shape[1], _ld(m), tm.data_ptr(), tm.shape[0], _ld(tm),
+                                       res.data_ptr(), _ld(res), _stream(m)))
+    return res
+
+
+# --------------------------------------------------------------------------------------------
+# scale fits
+# --------------------------------------------------------------------------------------------
+
+def _workspace(w: torch.Tensor) -> torch.Tensor:
+    nbytes = int(_lib.tvl_fit_scale_workspace_bytes(w.shape[0], w.shape[1]))
+    return torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=w.device)
+
+
+def fit_ternary_scale(w: torch.Tensor, neuron_scale: str = "independent", kmeans_iter: int = 10, return_latent: bool = True):
+    """Ternary scale by the reference's masked-mean iteration (``binary/modules.py:280-293``).
+    Returns ``(latent, scale)``: ``latent = clip(w / m, -1, 1)`` ``[N, K]`` and ``scale = m`` ``[N]``.
+    Only ``neuron_scale == "uniform"`` fits one global scale; anything else is per row, like the
+    reference (``:281``)."""
+    w = _rows(_gpu(w, "fit_ternary_scale").detach(), "fit_ternary_scale")
+    if w.dtype != torch.float32:
+        w = w.float()
+    n, k = w.shape
+    scale = torch.empty((n,), dtype=torch.float32, device=w.device)
+    latent = torch.empty((n, k), dtype=torch.float32, device=w.device) if return_latent else None
+    ws = _workspace(w)
+    with torch.cuda.device(w.device):
+        _check(_lib.tvl_fit_ternary_scale_f32(w.data_ptr(), n, k, _ld(w), 1 if neuron_scale == "uniform" else 0,
+                                              int(kmeans_iter), scale.data_ptr(),
+                                              latent.data_ptr() if latent is not None else None, k, ws.data_ptr(),
+                                              ws.numel() * 8, _stream(w)))
+    return latent, scale
+
+
+def fit_binary_scale(w: torch.Tensor, quantization: str = "binary", neuron_scale: str = "uniform", scaling="none",
+                     return_latent: bool = True):
+    """Binary / binary01 scale and latent weights (``binary/modules.py:193-266``)."""
+    if quantization not in ("binary", "binary01"):
+        raise ValueError(f"Unknown quantization: {quantization}")
+    if neuron_scale not in ("uniform", "independent"):
+        raise ValueError(f"Unknown neuron scaling method: {neuron_scale}")
+    w = _rows(_gpu(w, "fit_binary_scale").detach(), "fit_binary_scale")
+    if w.dtype != torch.float32:
+        w = w.float()
+    natural, prescale = 0, 1.0
+    if scaling is None or scaling == "none":
+        pass
+    elif isinstance(scaling, float):
+        prescale = scaling
+    elif scaling == "std":
+        prescale = 1.0 / float(w.std())  # torch's unbiased estimator, like the reference (modules.py:219-220)
+    elif scaling == "natural":
+        natural = 1
+    else:
+        raise ValueError(f"Unknown scaling method: {scaling}")
+    n, k = w.shape
+    scale = torch.empty((n,), dtype=torch.float32, device=w.device)
+    latent = torch.empty((n, k), dtype=torch.float32, device=w.device) if return_latent else None
+    ws = _workspace(w)
+    with torch.cuda.device(w.device):
+        _check(_lib.tvl_fit_binary_scale_f32(w.data_ptr(), n, k, _ld(w), _QUANT[quantization],
+                                             1 if neuron_scale == "uniform" else 0, float(prescale), natural,
+                                             scale.data_ptr(), latent.data_ptr() if latent is not None else None, k,
+                                             ws.data_ptr(), ws.numel() * 8, _stream(w)))
+    return latent, scale

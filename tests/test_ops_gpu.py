@@ -1,0 +1,426 @@
+"""Parity of the HIP operators (called through the C ABI) against the CPU oracle.  Needs an MI355X.
+
+Bars: bit-exact for every integer / byte result (quantize, pack, unpack, zero_out); for the
+matmul, bit-exact on dyadic-grid inputs (every partial sum is exact in float32, so the result
+does not depend on summation order) and <= 1e-5 absolute against a float64 oracle for N(0,1)
+inputs at the small sizes where float32 accumulation error stays below that.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ternary_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy() if t.dtype in (torch.bfloat16, torch.float16) else t.detach().cpu().numpy()
+
+
+def _grid(rng, shape):
+    return rng.integers(-64, 65, size=shape).astype(np.float32) / 64.0
+
+
+# ------------------------------------------------------------------------------ plumbing ops
+
+def test_zero_out_kats(ops, dev, golden_dir):
+    kats = json.load(open(os.path.join(golden_dir, "reference_kats.json")))["zero_out"]
+    for case in kats:
+        got = ops.zero_out(torch.tensor(case["input"], dtype=torch.int32, device=dev))
+        assert got.cpu().tolist() == case["expected"]
+    # list input like the reference's own test (zero_out_tests.py:9)
+    assert ops.zero_out([[5, 4, 3, 2, 1], [10, 9, 8, 7, 6]]).cpu()[0].tolist() == [5, 0, 0, 0, 0]
+    big = torch.arange(7, 7 + 100003, dtype=torch.int32, device=dev)
+    z = ops.zero_out(big)
+    assert int(z[0]) == 7 and int(z.abs().sum()) == 7
+    assert ops.zero_out(torch.empty((0,), dtype=torch.int32, device=dev)).numel() == 0
+
+
+def test_prevent_folding_is_identity(ops, dev):
+    for n in (0, 1, 15, 16, 17, 4096 * 1024 + 3):
+        c = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev)
+        w = torch.randn(4, device=dev)
+        assert torch.equal(ops.prevent_folding(c, w), c)
+    c = torch.randint(0, 256, (33, 7), dtype=torch.uint8, device=dev)
+    assert torch.equal(ops.prevent_folding(c[:, 1:], None), c[:, 1:])
+
+
+# ------------------------------------------------------------------------------ pack / unpack
+
+@pytest.mark.parametrize("n,k", [(1, 1), (1, 4), (3, 5), (8, 16), (7, 33), (64, 64), (5, 5031), (129, 1000), (16, 4096)])
+def test_pack_fn_matches_oracle(ops, dev, n, k):
+    rng = np.random.default_rng(n * 1000 + k)
+    t = rng.integers(-1, 2, size=(n, k)).astype(np.int8)
+    got = ops.pack_fn(torch.from_numpy(t).to(dev))
+    assert got.shape == (n, (k + 3) // 4) and got.dtype == torch.uint8
+    assert np.array_equal(got.cpu().numpy(), O.pack_format_c(t))
+    # strided input rows (unit stride inside a row)
+    wide = torch.zeros((n, k + 13), dtype=torch.int8, device=dev)
+    wide[:, 5:5 + k] = torch.from_numpy(t).to(dev)
+    assert np.array_equal(ops.pack_fn(wide[:, 5:5 + k]).cpu().numpy(), O.pack_format_c(t))
+    # round trip (impl/tf/moondream/ternary_tests.py:17-25 property)
+    back = ops.unpack_ternary(got, k, dtype=torch.int8)
+    assert np.array_equal(back.cpu().numpy(), t)
+
+
+def test_pack_examples_and_reference_buffer(ops, dev, golden_dir):
+    ex = json.load(open(os.path.join(golden_dir, "pack_examples.json")))
+    for case in ex["format_c"]:
+        t = torch.tensor(case["values"], dtype=torch.int8, device=dev)
+        assert ops.pack_fn(t).cpu().tolist() == case["bytes"]
+    for fmt in ("a", "b"):
+        for case in ex[f"format_{fmt}"]:
+            t = torch.tensor(case["values"], dtype=torch.int8, device=dev)
+            assert ops.pack_ternary_planar(t, fmt).cpu().tolist() == case["bytes"]
+    # the reference allocates K//4 + (4 - K%4) bytes per row when K%4 != 0 (ternary.py:269-270):
+    # packing into / unpacking from such an over-sized buffer must work
+    k = 13
+    t = torch.randint(-1, 2, (6, k), dtype=torch.int8, device=dev)
+    buf = torch.full((6, ops.reference_row_bytes(k)), 0xAB, dtype=torch.uint8, device=dev)
+    ops.pack_fn(t, out=buf)
+    assert torch.equal(ops.unpack_ternary(buf, k, dtype=torch.int8), t)
+    assert torch.all(buf[:, (k + 3) // 4:] == 0xAB)  # bytes beyond ceil(K/4) are untouched
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16, torch.int8])
+def test_unpack_dtypes_and_invalid_code(ops, dev, dtype):
+    pw = torch.arange(256, dtype=torch.uint8, device=dev).reshape(8, 32)  # every byte value, code 3 included
+    for k in (128, 127, 125, 1):
+        got = ops.unpack_ternary(pw, k, dtype=dtype)
+        want = O.unpack_format_c(pw.cpu().numpy(), k)
+        assert got.dtype == dtype and np.array_equal(_np(got).astype(np.float32), want)
+
+
+@pytest.mark.parametrize("fmt", ["a", "b"])
+def test_planar_formats(ops, dev, fmt, golden_dir):
+    n = json.load(open(os.path.join(golden_dir, "reference_kats.json")))["roundtrip_length"]["length"]
+    pack = O.pack_format_a if fmt == "a" else O.pack_format_b
+    unpack = O.unpack_format_a if fmt == "a" else O.unpack_format_b
+    for length in (n, 1, 4, 7, 1 << 16):
+        rng = np.random.default_rng(length)
+        t = rng.integers(-1, 2, size=(length,)).astype(np.int8)
+        got = ops.pack_ternary_planar(torch.from_numpy(t).to(dev), fmt)
+        assert np.array_equal(got.cpu().numpy(), pack(t))
+        back = ops.unpack_ternary_planar(got, fmt)
+        assert np.array_equal(back.cpu().numpy(), unpack(pack(t)))
+        assert np.array_equal(back.cpu().numpy()[:length].astype(np.int8), t)
+    allb = torch.arange(256, dtype=torch.uint8, device=dev)
+    assert np.array_equal(ops.unpack_ternary_planar(allb, fmt).cpu().numpy(), unpack(allb.cpu().numpy()))
+
+
+# ------------------------------------------------------------------------------ quantize + pack
+
+def test_quantizers_on_golden_inputs(ops, dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "quantizers.npz"))
+    for key in ("x_grid", "x"):
+        x = g[key]
+        xt = torch.from_numpy(x).to(dev)
+        for name, fn in (("ternary", O.ternarize), ("binary", O.binarize_sign), ("binary01", O.binarize_step)):
+            got = ops.quantize(xt, name)
+            assert np.array_equal(got.cpu().numpy(), fn(x)), (key, name)
+            assert np.array_equal(ops.quantize(xt, name, dtype=torch.int8).cpu().numpy(), fn(x).astype(np.int8))
+    # bit-equal to the reference's own output where its straight-through term is exact
+    got = ops.quantize(torch.from_numpy(g["x_grid"]).to(dev), "ternary").cpu().numpy()
+    assert np.array_equal(got, g["ternary_grid"])
+
+
+@pytest.mark.parametrize("n,k", [(1, 16), (4, 1024), (3, 1040), (5, 2048 + 16), (2, 4096), (7, 5031), (9, 30), (33, 768)])
+@pytest.mark.parametrize("quant", ["ternary", "binary", "binary01"])
+def test_ternarize_pack_matches_oracle(ops, dev, n, k, quant):
+    rng = np.random.default_rng(n * 7919 + k)
+    w = rng.uniform(-1, 1, size=(n, k)).astype(np.float32)
+    w.reshape(-1)[:6] = [0.5, -0.5, 0.49999997, -0.49999997, 0.0, -0.0][: min(6, w.size)]
+    want = O.pack_format_c(O.QUANTIZERS[quant](w))
+    got = ops.ternarize_pack(torch.from_numpy(w).to(dev), 0.5, quant)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_ternarize_pack_half_types(ops, dev, dtype):
+    torch.manual_seed(5)
+    for n, k in ((6, 2048), (5, 100)):
+        w = (torch.rand(n, k, device=dev) * 2 - 1).to(dtype)
+        w[0, :4] = torch.tensor([0.5, -0.5, 0.4998, -0.4998]).to(dtype)
+        want = O.pack_format_c(O.ternarize(_np(w)))
+        assert np.array_equal(ops.ternarize_pack(w).cpu().numpy(), want)
+
+
+def test_ternarize_pack_threshold_and_strides(ops, dev):
+    rng = np.random.default_rng(3)
+    w = rng.normal(size=(8, 256)).astype(np.float32)
+    for thr in (0.0, 0.25, 1.5):
+        want = O.pack_format_c(O.ternarize(w, thr))
+        assert np.array_equal(ops.ternarize_pack(torch.from_numpy(w).to(dev), thr).cpu().numpy(), want)
+    big = torch.from_numpy(rng.normal(size=(8, 512)).astype(np.float32)).to(dev)
+    view = big[:, 128:384]  # row stride 512, 16-byte aligned start: fast path with ld_w != k
+    assert np.array_equal(ops.ternarize_pack(view).cpu().numpy(), O.pack_format_c(O.ternarize(view.cpu().numpy())))
+    view = big[:, 3:259]    # misaligned start: generic path
+    assert np.array_equal(ops.ternarize_pack(view).cpu().numpy(), O.pack_format_c(O.ternarize(view.cpu().numpy())))
+    w = torch.tensor([[float("nan"), float("inf"), -float("inf"), 0.5]], device=dev)
+    assert ops.ternarize_pack(w).cpu().tolist() == [[0b10001001]]  # nan -> 0, +inf -> +1, -inf -> -1, 0.5 -> +1
+
+
+def test_ternarize_pack_full_size(ops, dev):
+    """4096 x 4096 (the benchmark's weight matrix): every byte against the oracle."""
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    w = torch.rand(4096, 4096, generator=g) * 2 - 1
+    w[0, :4] = torch.tensor([0.5, -0.5, 0.4999, -0.4999])
+    got = ops.ternarize_pack(w.to(dev)).cpu().numpy()
+    want = O.pack_format_c(O.ternarize(w.numpy()))
+    assert got.shape == (4096, 1024) and np.array_equal(got, want)
+    # round trip back to the ternary values
+    back = ops.unpack_ternary(torch.from_numpy(got).to(dev), 4096, dtype=torch.int8).cpu().numpy()
+    assert np.array_equal(back, O.ternarize(w.numpy()).astype(np.int8))
+
+
+# ------------------------------------------------------------------------------ the fused matmul
+
+def _case(rng, m, n, k, grid=True, bias=True):
+    x = _grid(rng, (m, k)) if grid else rng.normal(size=(m, k)).astype(np.float32)
+    t = rng.integers(-1, 2, size=(n, k)).astype(np.int8)
+    pw = O.pack_format_c(t)
+    scale = rng.uniform(0.5, 1.5, size=(n,)).astype(np.float32)
+    b = rng.normal(size=(n,)).astype(np.float32) if bias else None
+    return x, pw, scale, b
+
+
+SHAPES = [(1, 1, 1), (1, 8, 4), (3, 5, 7), (17, 33, 30), (64, 64, 64), (65, 130, 100), (5, 48, 5031),  # generic kernel
+          (1, 128, 64), (7, 100, 128), (32, 128, 256), (33, 64, 192), (64, 256, 512), (100, 300, 640),  # MFMA, small tiles
+          (129, 129, 64), (200, 512, 1024), (745, 2048, 2048)]
+
+
+@pytest.mark.parametrize("m,n,k", SHAPES)
+@pytest.mark.parametrize("xdt", [torch.float16, torch.bfloat16, torch.float32])
+def test_matmul_exact_grid(ops, dev, m, n, k, xdt):
+    rng = np.random.default_rng(m * 100003 + n * 1009 + k)
+    x, pw, scale, b = _case(rng, m, n, k)
+    want = O.ternary_matmul(x, pw, scale, b, 100.0)
+    xt = torch.from_numpy(x).to(dev).to(xdt)  # k/64 with |k| <= 64 is exact in f16 and bf16
+    got = ops.ternary_matmul(xt, torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev), torch.from_numpy(b).to(dev),
+                             100.0, out_dtype=torch.float32)
+    assert got.shape == (m, n) and got.dtype == torch.float32
+    assert np.array_equal(got.cpu().numpy(), want)  # max|delta| = 0: every partial sum is exact
+    # output in the activation dtype: one rounding of the same float32 value
+    got_lp = ops.ternary_matmul(xt, torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev), torch.from_numpy(b).to(dev), 100.0)
+    assert got_lp.dtype == xdt
+    assert torch.equal(got_lp.cpu(), torch.from_numpy(want).to(xdt))
+
+
+@pytest.mark.parametrize("m,n,k", [(9, 40, 52), (130, 257, 256), (300, 512, 512)])
+def test_matmul_no_bias_clip_and_batch_dims(ops, dev, m, n, k):
+    rng = np.random.default_rng(k)
+    x, pw, scale, _ = _case(rng, m, n, k, bias=False)
+    for clip in (100.0, 2.5, -2.5):  # the reference stores abs(max_val) (binary/modules.py:99)
+        want = O.ternary_matmul(x, pw, scale, None, clip)
+        got = ops.ternary_matmul(torch.from_numpy(x).to(dev).half(), torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev),
+                                 None, clip, out_dtype=torch.float32)
+        assert np.array_equal(got.cpu().numpy(), want)
+        assert np.max(np.abs(want)) <= abs(clip)
+    x3 = torch.from_numpy(x).to(dev).half().reshape(1, m, k).expand(2, m, k)
+    got = ops.ternary_matmul(x3, torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev), None, 100.0, out_dtype=torch.float32)
+    assert got.shape == (2, m, n)
+    assert np.array_equal(got[1].cpu().numpy(), O.ternary_matmul(x, pw, scale, None, 100.0))
+
+
+@pytest.mark.parametrize("k", [64, 60])
+def test_matmul_invalid_code_and_padding(ops, dev, k):
+    """Random bytes (code 3 included, as in the reference's random pw initialiser,
+    impl/tf/moondream/ternary.py:272-276) decode as code-1; pad codes beyond K never contribute."""
+    rng = np.random.default_rng(11)
+    m, n = 40, 96
+    x = _grid(rng, (m, k))
+    pw = rng.integers(0, 256, size=(n, (k + 3) // 4 + 3)).astype(np.uint8)  # wider rows than needed
+    scale = np.ones((n,), np.float32)
+    want = O.ternary_matmul(x, pw[:, : (k + 3) // 4], scale, None, 1e4, k=k)
+    pwt = torch.from_numpy(pw).to(dev)
+    for xdt in (torch.float16, torch.float32):
+        got = ops.ternary_matmul(torch.from_numpy(x).to(dev).to(xdt), pwt, torch.from_numpy(scale).to(dev), None, 1e4,
+                                 out_dtype=torch.float32)
+        assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_matmul_strided_inputs(ops, dev):
+    rng = np.random.default_rng(21)
+    m, n, k = 70, 130, 128
+    x, pw, scale, b = _case(rng, m, n, k)
+    want = O.ternary_matmul(x, pw, scale, b, 100.0)
+    xw = torch.zeros((m, k + 64), dtype=torch.float16, device=dev)
+    xw[:, 8:8 + k] = torch.from_numpy(x).to(dev).half()
+    pww = torch.zeros((n, k // 4 + 24), dtype=torch.uint8, device=dev)
+    pww[:, 8:8 + k // 4] = torch.from_numpy(pw).to(dev)
+    args = (torch.from_numpy(scale).to(dev), torch.from_numpy(b).to(dev), 100.0)
+    got = ops.ternary_matmul(xw[:, 8:8 + k], pww[:, 8:8 + k // 4], *args, out_dtype=torch.float32)   # aligned views: MFMA path
+    assert np.array_equal(got.cpu().numpy(), want)
+    xw[:, 3:3 + k] = torch.from_numpy(x).to(dev).half()
+    pww[:, 5:5 + k // 4] = torch.from_numpy(pw).to(dev)
+    got = ops.ternary_matmul(xw[:, 3:3 + k], pww[:, 5:5 + k // 4], *args, out_dtype=torch.float32)   # misaligned: generic path
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("m,n,k", [(16, 64, 96), (150, 256, 256), (64, 128, 4096)])
+def test_matmul_randn_vs_f64(ops, dev, m, n, k):
+    """N(0,1) activations: float32 accumulation against the float64 oracle.
+
+    1e-5 absolute holds while the sums stay small (K <= 96 here).  Beyond that no float32
+    summation order meets it - the reference's own two CPU paths (BLAS matmul and the
+    select-and-sum loop) already differ by 3.4e-5 at K = 256 - so the gate there is "no worse than
+    twice the error of a float32 CPU evaluation of the same product against the same oracle"."""
+    rng = np.random.default_rng(1234)
+    x, pw, scale, b = _case(rng, m, n, k, grid=False)
+    want = O.ternary_matmul(x, pw, scale, b, 1e6)
+    cpu_f32 = O.ternary_matmul(x, pw, scale, b, 1e6, acc_dtype=np.float32)  # float32 BLAS order
+    err_cpu = float(np.max(np.abs(cpu_f32 - want)))
+    tol = 1e-5 if k <= 96 else max(1e-5, 2.0 * err_cpu)
+    dev_args = (torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev), torch.from_numpy(b).to(dev), 1e6)
+    got = ops.ternary_matmul(torch.from_numpy(x).to(dev), *dev_args)
+    err = float(np.max(np.abs(got.cpu().numpy() - want)))
+    print(f"f32 x: K={k} max|gpu-f64|={err:.3e}  max|cpu_f32-f64|={err_cpu:.3e}")
+    assert err <= tol
+    # f16 / bf16 activations (matrix-core path when K % 64 == 0): the oracle sees the same rounded inputs
+    for xdt in (torch.float16, torch.bfloat16):
+        xr = torch.from_numpy(x).to(xdt)
+        want_r = O.ternary_matmul(xr.float().numpy(), pw, scale, b, 1e6)
+        got_r = ops.ternary_matmul(xr.to(dev), *dev_args, out_dtype=torch.float32)
+        err_r = float(np.max(np.abs(got_r.cpu().numpy() - want_r)))
+        print(f"{xdt}: K={k} max|gpu-f64|={err_r:.3e}")
+        assert err_r <= tol
+
+
+def test_matmul_gelu_epilogue(ops, dev):
+    rng = np.random.default_rng(8)
+    for m, n, k in ((20, 50, 36), (140, 256, 128)):
+        x, pw, scale, b = _case(rng, m, n, k)
+        scale *= 0.1
+        want = O.ternary_matmul(x, pw, scale, b, 100.0, act=O.ACT_GELU_TANH)
+        got = ops.ternary_matmul(torch.from_numpy(x).to(dev).half(), torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev),
+                                 torch.from_numpy(b).to(dev), 100.0, activation="gelu_tanh", out_dtype=torch.float32)
+        assert np.max(np.abs(got.cpu().numpy() - want)) <= 1e-5  # float32 tanh vs float64 oracle
+
+
+def test_matmul_matches_reference_forward_golden(ops, dev, golden_dir):
+    """Golden outputs of the reference's ScaledTernaryLinear / ScaledBinary*Linear forward."""
+    g = np.load(os.path.join(golden_dir, "scaled_linear_forward.npz"))
+    for quant in ("ternary", "binary", "binary01"):
+        for bias in (True, False):
+            tag = f"{quant}_{'bias' if bias else 'nobias'}"
+            pw = ops.ternarize_pack(torch.from_numpy(g[f"{tag}_w"]).to(dev), 0.5, quant)
+            b = torch.from_numpy(g[f"{tag}_b"]).to(dev) if bias else None
+            for xdt in (torch.float32, torch.float16):
+                got = ops.ternary_matmul(torch.from_numpy(g[f"{tag}_x"]).to(dev).to(xdt), pw, torch.from_numpy(g[f"{tag}_scale"]).to(dev),
+                                         b, float(g[f"{tag}_maxval"]), out_dtype=torch.float32)
+                assert np.array_equal(got.cpu().numpy(), g[f"{tag}_y"]), (tag, xdt)
+    for bias in (True, False):  # uniform latent weights: the reference's weights are 1 ulp off +-1
+        tag = f"ternary_u_{'bias' if bias else 'nobias'}"
+        pw = ops.ternarize_pack(torch.from_numpy(g[f"{tag}_w"]).to(dev))
+        b = torch.from_numpy(g[f"{tag}_b"]).to(dev) if bias else None
+        got = ops.ternary_matmul(torch.from_numpy(g[f"{tag}_x"]).to(dev), pw, torch.from_numpy(g[f"{tag}_scale"]).to(dev), b,
+                                 float(g[f"{tag}_maxval"]))
+        assert np.max(np.abs(got.cpu().numpy() - g[f"{tag}_y"])) <= 1e-5
+    pw = ops.ternarize_pack(torch.from_numpy(g["ternary_randn_w"]).to(dev))
+    got = ops.ternary_matmul(torch.from_numpy(g["ternary_randn_x"]).to(dev), pw, torch.from_numpy(g["ternary_randn_scale"]).to(dev),
+                             torch.from_numpy(g["ternary_randn_b"]).to(dev), float(g["ternary_randn_maxval"]))
+    assert np.max(np.abs(got.cpu().numpy() - g["ternary_randn_y"])) <= 5e-5  # two float32 summation orders at K=256
+
+
+def test_matmul_full_size_4096(ops, dev):
+    """The benchmark configuration, 4096 x 4096 x 4096 f16 on the exact grid: all 16.7M outputs
+    against a float32 matmul of the unpacked weights (exact on this grid, so any correct
+    implementation gives the same bits), plus 64 rows against the CPU oracle."""
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    m = n = k = 4096
+    x = (torch.randint(-64, 65, (m, k), generator=g).float() / 64.0)
+    w = torch.rand(n, k, generator=g) * 2 - 1
+    scale = torch.rand(n, generator=g) + 0.5
+    bias = torch.randn(n, generator=g)
+    pw = ops.ternarize_pack(w.to(dev))
+    y = ops.ternary_matmul(x.to(dev).half(), pw, scale.to(dev), bias.to(dev), 100.0, out_dtype=torch.float32)
+    wt = ops.unpack_ternary(pw, k)
+    acc = x.to(dev) @ wt.t()
+    ref = torch.clip(acc * scale.to(dev) + bias.to(dev), -100.0, 100.0)
+    assert torch.equal(y, ref)
+    rows = torch.randint(0, m, (64,), generator=g)
+    want = O.ternary_matmul(x[rows].numpy(), pw.cpu().numpy(), scale.numpy(), bias.numpy(), 100.0)
+    assert np.array_equal(y[rows.to(dev)].cpu().numpy(), want)
+    # linearity in x (size-independent property): f(2x) - bias-part == 2 (f(x) - bias-part) before clipping
+    y2 = ops.ternary_matmul((2 * x).to(dev).half(), pw, scale.to(dev), None, 1e9, out_dtype=torch.float32)
+    y1 = ops.ternary_matmul(x.to(dev).half(), pw, scale.to(dev), None, 1e9, out_dtype=torch.float32)
+    assert torch.equal(y2, 2 * y1)
+
+
+def test_ternary_mm(ops, dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "ternary_mm.npz"))
+    for size in (32, 256):
+        got = ops.ternary_mm(torch.from_numpy(g[f"m{size}"]).to(dev), torch.from_numpy(g[f"tm{size}"]).to(dev))
+        assert np.array_equal(got.cpu().numpy(), g[f"res{size}"])
+    got = ops.ternary_mm(torch.from_numpy(g["m256r"]).to(dev), torch.from_numpy(g["tm256r"]).to(dev))
+    assert np.max(np.abs(got.cpu().numpy() - g["res256r"])) <= 1e-4  # float32 order noise at K=256, |sum| ~ 16
+    rng = np.random.default_rng(2)
+    m, tm = _grid(rng, (37, 101)), rng.normal(size=(19, 101)).astype(np.float32)
+    assert np.array_equal(ops.ternary_mm(torch.from_numpy(m).to(dev), torch.from_numpy(tm).to(dev)).cpu().numpy(), O.ternary_mm(m, tm))
+
+
+# ------------------------------------------------------------------------------ scale fits
+
+def test_fit_scales_match_reference_golden(ops, dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "linear_to_quantized.npz"))
+    w = torch.from_numpy(g["w"]).to(dev)
+    for key in g.files:
+        if not key.endswith("__scale"):
+            continue
+        quant, ns, sc = key.split("__")[:3]
+        try:
+            sc = float(sc)
+        except ValueError:
+            pass
+        if quant == "ternary":
+            latent, scale = ops.fit_ternary_scale(w, ns)
+        else:
+            latent, scale = ops.fit_binary_scale(w, quant, ns, sc)
+        np.testing.assert_allclose(scale.cpu().numpy(), g[key], rtol=1e-5, err_msg=key)
+        np.testing.assert_allclose(latent.cpu().numpy(), g[key.replace("__scale", "__latent")], rtol=1e-5, atol=1e-6, err_msg=key)
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (3, 7), (64, 2048), (300, 1000)])
+def test_fit_ternary_scale_vs_oracle(ops, dev, n, k):
+    rng = np.random.default_rng(n + k)
+    w = (rng.normal(size=(n, k)) * 0.05).astype(np.float32)
+    for ns in ("independent", "uniform"):
+        latent, scale = ops.fit_ternary_scale(torch.from_numpy(w).to(dev), ns)
+        lo, so = O.fit_ternary_scale(w, ns)
+        np.testing.assert_allclose(scale.cpu().numpy(), so, rtol=2e-5)
+        np.testing.assert_allclose(latent.cpu().numpy(), lo, rtol=2e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        ops.fit_binary_scale(torch.from_numpy(w).to(dev), "binary", "none")
+
+
+# ------------------------------------------------------------------------------ error behaviour
+
+def test_errors(ops, dev):
+    x = torch.zeros((4, 64), dtype=torch.float16, device=dev)
+    pw = torch.zeros((8, 16), dtype=torch.uint8, device=dev)
+    s = torch.ones(8, device=dev)
+    with pytest.raises(ValueError):
+        ops.ternary_matmul(x.cpu(), pw, s, None, 1.0)                # CPU tensor: no CPU path
+    with pytest.raises(ValueError):
+        ops.ternary_matmul(x, pw[:, :15], s, None, 1.0)              # packed rows too short for K
+    with pytest.raises(ValueError):
+        ops.ternary_matmul(x, pw, s[:7], None, 1.0)                  # scale length
+    with pytest.raises(ValueError):
+        ops.ternary_matmul(x.to(torch.int32), pw, s, None, 1.0)      # dtype
+    with pytest.raises(ValueError):
+        ops.ternary_matmul(x, pw, s, None, 1.0, activation="relu")   # unknown option string
+    with pytest.raises(ValueError):
+        ops.pack_fn(torch.zeros((2, 2), dtype=torch.float32, device=dev))
+    with pytest.raises(ValueError):
+        ops.unpack_ternary(pw, 65)
+    with pytest.raises(ValueError):
+        ops.ternarize_pack(torch.zeros((2, 8), device=dev), quantization="quaternary")
+    # empty shapes are fine
+    assert ops.ternary_matmul(x[:0], pw, s, None, 1.0).shape == (0, 8)
+    assert ops.pack_fn(torch.zeros((0, 8), dtype=torch.int8, device=dev)).shape == (0, 2)
+    # the process survives all of the above and still computes
+    assert float(ops.ternary_matmul(x + 1, pw + 0xAA, s, None, 1e4).sum()) == 4 * 8 * 64
