@@ -1,0 +1,257 @@
+"""Benchmark of the packed ternary GEMM hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--m 4096 --n 4096 --k 4096] [--sweep] [--no-cpu]
+
+One step = one `ternary_matmul` (packed {-1,0,+1} weights x f16 activations, fused scale/bias/clip)
+over one synthetic batch resident in HBM: M x K activations against an N x K weight matrix that was
+ternarized and packed once, outside the timed region.  Default workload: 4096 x 4096 x 4096 (the
+configuration the headline metric is quoted on).  With N > 1 ranks (one per GPU, launched by
+torch.distributed.run) rank 0 quantizes + packs, the 2-bit weights are broadcast over RCCL, and each
+rank runs the same M-row shard size (weak scaling, no collective on the timed path).
+
+Rank 0 prints ONE JSON line.  `value` = total ternary-GEMM operations (2 M N K per step, all ranks)
+per second in GOPS.  `roofline` prices the GEMM kernel against the dense f16 matrix-core peak (this
+shape is compute-bound, 1 927 op/byte); `hbm` gives the same launch as a fraction of HBM bandwidth
+(the metric's second half) plus the HBM-bound kernels of the path (quantize+pack, skinny-M GEMM).
+`cpu_baseline` times a CPU restatement of the reference op on the host's cores (bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 matrix-core peak
+
+
+def gemm_bytes(m, n, k, out_bytes=2):
+    """Algorithmic bytes of one launch: x f16 + packed W + scale,bias f32 + y."""
+    return m * k * 2 + n * ((k + 3) // 4) + 2 * n * 4 + m * n * out_bytes
+
+
+def time_launches(fn, steps, warmup):
+    """Average device time of fn() in ms, measured with events on the current stream (the stream the
+    kernels are launched on)."""
+    for _ in range(warmup):
+        fn(0)
+    torch.cuda.synchronize()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    for i in range(steps):
+        starts[i].record()
+        fn(i)
+        ends[i].record()
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
+def cpu_baseline(m_full, n, k, seed, budget_s=12.0):
+    """Reference-semantics CPU run on the host cores: ScaledTernaryLinear.forward restated with torch CPU
+    ops (binary/modules.py:101-109: ternarize on every call, dense float32 F.linear, *scale, +bias, clip)
+    on a bounded row sample of the same workload."""
+    threads = min(16, os.cpu_count() or 1)  # the GPU box gives one GPU's share of cores (16)
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(seed)
+    w = torch.rand(n, k, generator=g) * 2 - 1
+    scale = torch.rand(n, generator=g) + 0.5
+    bias = torch.randn(n, generator=g)
+
+    def fwd(x):
+        wq = (w >= 0.5).float() - (w <= -0.5).float()
+        y = torch.nn.functional.linear(x, wq)
+        y *= scale
+        y += bias
+        return y.clip(-100.0, 100.0)
+
+    ms = min(512, m_full)
+    x = torch.randint(-64, 65, (ms, k), generator=g).float() / 64.0
+    fwd(x)  # warm
+    t0 = time.perf_counter(); fwd(x); dt = time.perf_counter() - t0
+    # grow the sample towards the budget (bounded by the full M)
+    ms2 = int(min(m_full, max(ms, ms * (budget_s / 3.0) / max(dt, 1e-6))))
+    ms2 = max(64, (ms2 // 64) * 64)
+    x = torch.randint(-64, 65, (ms2, k), generator=g).float() / 64.0
+    reps, t_total = 0, 0.0
+    while t_total < budget_s and reps < 50:
+        t0 = time.perf_counter(); fwd(x); t_total += time.perf_counter() - t0
+        reps += 1
+    gops = 2.0 * ms2 * n * k * reps / t_total / 1e9
+    out = {"value": round(gops, 2), "unit": "GOPS", "cores": threads, "kind": "port",
+           "sample": f"{reps} x ScaledTernaryLinear.forward semantics in torch CPU float32 (per-call ternarize + dense matmul + "
+                     f"scale/bias/clip) on {ms2} of {m_full} rows, N={n}, K={k}"}
+    # the multiplication-free select-and-sum form (matrix_mul_tests.py:29-37) as a C/OpenMP port
+    try:
+        from __graft_entry__ import ORACLE_SO
+        lib = ctypes.CDLL(ORACLE_SO)
+        fnc = lib.tvo_ternary_matmul_select_f32
+        fnc.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_int]
+        from oracle import ternary_oracle as O
+        pw = np.ascontiguousarray(O.pack_format_c(O.ternarize(w.numpy())))
+        msel = 128
+        xs = np.ascontiguousarray(x[:msel].numpy())
+        ys = np.empty((msel, n), np.float32)
+        sc, bi = scale.numpy(), bias.numpy()
+        t0 = time.perf_counter()
+        rc = fnc(xs.ctypes.data, msel, k, pw.ctypes.data, pw.shape[1], n, sc.ctypes.data, bi.ctypes.data, 100.0, ys.ctypes.data, threads)
+        dt = time.perf_counter() - t0
+        if rc == 0:
+            out["select_and_sum_c_port_gops"] = round(2.0 * msel * n * k / dt / 1e9, 2)
+    except Exception as e:  # the C port is optional colour; the torch form above is the baseline
+        out["select_and_sum_c_port_gops"] = f"unavailable: {e}"
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=4096)
+    ap.add_argument("--sweep", action="store_true", help="also time the M sweep and the moondream layer shapes")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import ternary_vllm_amd as tv
+    ops = tv.custom_ops_mod
+
+    M, N, K = args.m, args.n, args.k
+    seed = 1234
+    g = torch.Generator().manual_seed(seed)
+    w_lat = torch.rand(N, K, generator=g) * 2 - 1          # latent weights U(-1,1): ~25/50/25 % -1/0/+1 at threshold 0.5
+    scale = (torch.rand(N, generator=g) + 0.5).to(dev)      # U(0.5, 1.5)
+    bias = torch.randn(N, generator=g).to(dev)
+
+    # ---- one-time quantize + pack on rank 0, 2-bit weights broadcast to the other ranks ---------
+    extra = {}
+    pw = torch.empty((N, (K + 3) // 4), dtype=torch.uint8, device=dev)
+    if rank == 0:
+        ops.ternarize_pack(w_lat.to(dev), 0.5, out=pw)
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        dist.broadcast(pw, src=0); dist.broadcast(scale, src=0); dist.broadcast(bias, src=0)
+        torch.cuda.synchronize()
+        extra["weight_broadcast_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        extra["weight_broadcast_bytes"] = pw.numel() + 8 * N
+
+    # ---- synthetic activations: rotate over several buffers so that no step re-reads a cache-warm x
+    nbuf = 6
+    gx = torch.Generator().manual_seed(seed + 1 + rank)
+    xs = [(torch.randn(M, K, generator=gx)).to(dev).half() for _ in range(nbuf)]
+    ys = [torch.empty((M, N), dtype=torch.float16, device=dev) for _ in range(nbuf)]
+
+    def step(i):
+        ops.ternary_matmul(xs[i % nbuf], pw, scale, bias, 100.0, out=ys[i % nbuf])
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ops_per_step = 2.0 * M * N * K * world
+    value = ops_per_step * args.steps / elapsed / 1e9
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel, from per-launch device time (events on the launch stream)
+        avg_ms, med_ms = time_launches(step, max(20, min(args.steps, 100)), 5)
+        flops = 2.0 * M * N * K
+        achieved_tf = flops / (avg_ms * 1e-3) / 1e12
+        by = gemm_bytes(M, N, K, 2)
+        roofline = {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved_tf / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "gemm_mfma_kernel<f16,f16,256,256>", "avg_launch_ms": round(avg_ms, 4),
+                    "median_launch_ms": round(med_ms, 4), "flops_per_launch": flops}
+        hbm = {"gemm_algorithmic_bytes": by, "gemm_GBps": round(by / (avg_ms * 1e-3) / 1e9, 1),
+               "gemm_frac_of_hbm_peak": round(by / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "note": "4096^3 with f16 activations is matrix-core bound (1927 op/B): its HBM fraction is capped near 16 %"}
+
+        # ---- HBM-bound kernel of the path: quantize + pack (f32 in, 2 bits out), cache-cold buffers
+        nw = 6  # 6 x 64 MiB of latent weights > 256 MiB Infinity Cache
+        wl = [torch.rand(N, K, device=dev) * 2 - 1 for _ in range(nw)]
+        pws = [torch.empty_like(pw) for _ in range(nw)]
+        p_avg, p_med = time_launches(lambda i: ops.ternarize_pack(wl[i % nw], 0.5, out=pws[i % nw]), 30, 6)
+        pack_bytes = N * K * 4 + N * ((K + 3) // 4)
+        hbm["pack_kernel"] = {"algorithmic_bytes": pack_bytes, "avg_launch_ms": round(p_avg, 4),
+                              "GBps": round(pack_bytes / (p_avg * 1e-3) / 1e9, 1),
+                              "frac_of_hbm_peak": round(pack_bytes / (p_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del wl, pws
+
+        if args.sweep:
+            sweep = []
+            shapes = [(mm, 4096, 4096) for mm in (1, 16, 64, 256, 1024, 4096)]
+            shapes += [(mm, nn, kk) for mm in (1, 745) for (nn, kk) in ((6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192))]
+            for (mm, nn, kk) in shapes:
+                nb = max(2, min(16, int(600e6 // max(1, nn * kk // 4 + mm * kk * 2))))  # rotate > 256 MiB where small
+                pwl = [torch.randint(0, 171, (nn, kk // 4), dtype=torch.uint8, device=dev) for _ in range(nb)]
+                xl = [torch.randn(mm, kk, device=dev).half() for _ in range(nb)]
+                yl = [torch.empty((mm, nn), dtype=torch.float16, device=dev) for _ in range(nb)]
+                sc = torch.ones(nn, device=dev); bi = torch.zeros(nn, device=dev)
+                a, md = time_launches(lambda i: ops.ternary_matmul(xl[i % nb], pwl[i % nb], sc, bi, 100.0, out=yl[i % nb]), 40, 8)
+                b_ = gemm_bytes(mm, nn, kk, 2)
+                sweep.append({"m": mm, "n": nn, "k": kk, "avg_ms": round(a, 5), "GOPS": round(2.0 * mm * nn * kk / (a * 1e-3) / 1e9, 1),
+                              "GBps": round(b_ / (a * 1e-3) / 1e9, 1), "frac_hbm": round(b_ / (a * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "frac_mfma": round(2.0 * mm * nn * kk / (a * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)})
+                del pwl, xl, yl
+            extra["sweep"] = sweep
+
+        result = {
+            "metric": "ternary GEMM GOPS + HBM GB/s (% roofline), 4096x4096x4096, 1 GPU" if world == 1 else
+                      "ternary GEMM GOPS + HBM GB/s (% roofline), 4096x4096x4096 per GPU",
+            "value": round(value, 1), "unit": "GOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{M}x{N}x{K} ternary x f16 GEMM, 2-bit packed weights, fused scale/bias/clip, f16 out",
+                       "m_per_gpu": M, "n": N, "k": K, "sharding": "rows of x (M) across ranks; packed weights replicated by broadcast"},
+            "roofline": roofline, "hbm": hbm,
+        }
+        if not args.no_cpu and world == 1:
+            result["cpu_baseline"] = cpu_baseline(M, N, K, seed)
+        else:
+            result["cpu_baseline"] = None
+        result.update(extra)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
