@@ -3,8 +3,8 @@
 //   y[m,n] = act(clip((sum_k x[m,k] * (code(pw[n,k]) - 1)) * scale[n] + bias[n]))
 //
 // Design (MI355X):
-//  * the activation tile goes global -> LDS directly (global_load_lds, 16 B per lane), double
-//    buffered, one barrier per 64-deep k step; the LDS image is XOR-swizzled through the SOURCE
+//  * the activation tile goes global -> LDS directly (global_load_lds, 16 B per lane), three
+//    tiles in flight, one barrier per 64-deep k step; the LDS image is XOR-swizzled through the SOURCE
 //    address (LDS-DMA writes lane-linear) so the 32-row fragment reads (ds_read_b128) are
 //    conflict-free;
 //  * the packed weights never touch LDS: each lane loads the 8 bytes (32 weights) of its own
@@ -14,12 +14,15 @@
 //    the wave's 4 (or 2) row tiles;
 //  * the k order inside a 64-step is permuted identically for both operands (lane half h takes
 //    k = 32h .. 32h+31) so that each lane's weight bytes are contiguous;
-//  * v_mfma_f32_32x32x16_{f16,bf16}, float32 accumulators, fused scale / bias / clip / GELU
-//    epilogue straight from the accumulator registers.
+//  * v_mfma_f32_32x32x16_{f16,bf16} with the weights as the "A" operand (accumulator rows = output
+//    channels), float32 accumulators, fused scale / bias / clip / GELU epilogue straight from the
+//    accumulator registers with 16-byte-per-lane stores (v_permlane32_swap between half-waves).
 // Requires k % 64 == 0, 16-byte aligned activation rows and 8-byte aligned packed rows; any m, n
 // (edge tiles clamp their loads and mask their stores).
 #include "tvl_common.h"
 #include "tvl_kernels.h"
+
+#include <type_traits>
 
 namespace tvl {
 
@@ -33,16 +36,31 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int BK = 64;             // k elements per pipeline step
 constexpr int ROW_BYTES = BK * 2;  // bytes of one activation row in the LDS tile
+constexpr int NBUF = 3;            // activation tiles in LDS
 
 // ---- 2-bit -> f16 decode -------------------------------------------------------------------
+// Constants live in registers the compiler cannot see through (set once per kernel by inline asm),
+// so that (rep & mask) | magic becomes ONE v_and_or_b32 instead of v_and + v_or with literals.
+struct DecodeConsts {
+    uint32_t mask01, mask23;  // scalar registers
+    uint32_t magic;           // vector register: 0x6400 in both halves (f16 1024.0)
+};
+__device__ __forceinline__ DecodeConsts make_decode_consts() {
+    DecodeConsts c;
+    asm volatile("s_mov_b32 %0, 0x000C0003" : "=s"(c.mask01));
+    asm volatile("s_mov_b32 %0, 0x00C00030" : "=s"(c.mask23));
+    asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(c.magic));
+    return c;
+}
+
 // `d` holds 16 codes; BYTE selects 4 of them (weights 4*BYTE .. 4*BYTE+3 of the dword).
 // Returns two registers: (w0, w1) and (w2, w3) as packed f16.
 template <int BYTE>
-__device__ __forceinline__ void decode4_f16(uint32_t d, uint32_t& r01, uint32_t& r23) {
+__device__ __forceinline__ void decode4_f16(uint32_t d, const DecodeConsts& c, uint32_t& r01, uint32_t& r23) {
     // rep = [byte, 0, byte, 0]: the selected byte in the low 8 bits of both 16-bit halves
     const uint32_t rep = __builtin_amdgcn_perm(d, d, 0x0C000C00u | BYTE | (BYTE << 16));
-    const uint32_t v01 = (rep & 0x000C0003u) | 0x64006400u;  // lo = 1024 + c0      hi = 1024 + 4 c1
-    const uint32_t v23 = (rep & 0x00C00030u) | 0x64006400u;  // lo = 1024 + 16 c2   hi = 1024 + 64 c3
+    const uint32_t v01 = (rep & c.mask01) | c.magic;  // lo = 1024 + c0      hi = 1024 + 4 c1
+    const uint32_t v23 = (rep & c.mask23) | c.magic;  // lo = 1024 + 16 c2   hi = 1024 + 64 c3
     const half2v m01 = {(_Float16)1.0f, (_Float16)0.25f}, a01 = {(_Float16)-1025.0f, (_Float16)-257.0f};
     const half2v m23 = {(_Float16)0.0625f, (_Float16)0.015625f}, a23 = {(_Float16)-65.0f, (_Float16)-17.0f};
     const half2v o01 = __builtin_elementwise_fma(__builtin_bit_cast(half2v, v01), m01, a01);
@@ -56,10 +74,10 @@ __device__ __forceinline__ uint32_t f16pair_to_bf16pair(uint32_t f) { return f |
 
 // 8 weights (one halfword: HW = 0..1 of the dword) -> one MFMA B fragment
 template <typename TX, int HW>
-__device__ __forceinline__ uint4 decode8(uint32_t d) {
+__device__ __forceinline__ uint4 decode8(uint32_t d, const DecodeConsts& c) {
     uint4 r;
-    decode4_f16<2 * HW>(d, r.x, r.y);
-    decode4_f16<2 * HW + 1>(d, r.z, r.w);
+    decode4_f16<2 * HW>(d, c, r.x, r.y);
+    decode4_f16<2 * HW + 1>(d, c, r.z, r.w);
     if constexpr (sizeof(TX) == 2 && !__is_same(TX, f16)) {
         r.x = f16pair_to_bf16pair(r.x); r.y = f16pair_to_bf16pair(r.y);
         r.z = f16pair_to_bf16pair(r.z); r.w = f16pair_to_bf16pair(r.w);
@@ -96,7 +114,7 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
     constexpr int A_TILE_BYTES = BM * ROW_BYTES;
     constexpr int ROUNDS = (BM * 8) / NT;                // 16-byte pieces per thread per tile
     static_assert((BM * 8) % NT == 0, "tile/threads mismatch");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * A_TILE_BYTES
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NBUF * A_TILE_BYTES
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -115,11 +133,19 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
         gm = gm < m ? gm : m - 1;
         a_src[i] = x + (int64_t)gm * ld_x + chunk * 8;
     }
+    // LDS-DMA issued from inline asm: hipcc then neither counts it nor orders the fragment reads of
+    // the OTHER buffer behind it (with the builtin it drains vmcnt(0) before the first ds_read of every
+    // step, which serialises load and compute).  Completion is waited for by hand: every wave's
+    // s_waitcnt vmcnt(0) at the top of the next step, then the barrier.
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
     auto stage_a = [&](int kb, int buf) {
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
-            unsigned char* dst = lds + buf * A_TILE_BYTES + (i * NT + wid * 64) * 16;  // wave-uniform
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (int64_t)kb * BK), (lptr_t)dst, 16, 0, 0);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + buf * A_TILE_BYTES + (i * NT + wid * 64) * 16);
+            const TX* src = a_src[i] + (int64_t)kb * BK;
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
         }
     };
 
@@ -148,56 +174,180 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
             for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.0f;
 
     const int nk = k / BK;
-    uint2 bq[TN], bq_next[TN];
+    const DecodeConsts dc = make_decode_consts();
+
+    // Pipeline (NBUF = 3 LDS tiles): at the middle of step kb every wave waits for its own pieces of
+    // tile kb+1 (issued a whole step earlier), one barrier publishes them and retires all reads of
+    // tile kb-1, whose buffer tile kb+2 is then loaded into.  Fragments (LDS reads and weight decode)
+    // are fetched one 16-deep sub-step ahead of the MFMAs that use them, across step boundaries, so
+    // the matrix pipe never drains at the barrier.
+    // All loads of the loop are issued from inline asm and waited for by hand (one s_waitcnt vmcnt(0) per
+    // step): hipcc's own counted waits only see the loads it emitted and would drain the LDS-DMA queue
+    // early.  The wait statement names the weight registers it completes ("+v"), which orders every
+    // consumer behind it.  The loop is unrolled by NBUF so that buffers and registers have static roles
+    // (no rotation copies of registers whose loads are still in flight).
+    uint64_t bq0[TN], bq1[TN], bq2[TN];  // packed weights (32 per lane and tile) of steps 3j, 3j+1, 3j+2
+    auto load_b = [&](int kb, uint64_t (&dst)[TN]) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[t]) : "v"(b_src[t] + (int64_t)kb * (BK / 4)) : "memory");
+    };
+    auto wait_loads = [&](uint64_t (&q)[TN]) {
+        if constexpr (TN == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]) : : "memory");
+        else if constexpr (TN == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]) : : "memory");
+        else static_assert(TN <= 2, "extend wait_loads");
+    };
+    auto read_a = [&](int buf, int s, uint4 (&af)[TM]) {
+        const unsigned char* abase = lds + buf * A_TILE_BYTES + a_row_off + a_col_off[s];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(abase + i * 32 * ROW_BYTES);
+    };
+    auto decode_b = [&](const uint64_t (&bq)[TN], int s, uint4 (&bf)[TN]) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const uint32_t d = (s < 2) ? (uint32_t)bq[t] : (uint32_t)(bq[t] >> 32);
+            bf[t] = (s & 1) ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc);
+        }
+    };
+    auto mma = [&](const uint4 (&af)[TM], const uint4 (&bf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[i][t] = mfma32<TX>(bf[t], af[i], acc[i][t]);
+    };
+
+    // scheduling hint for one sub-step: each MFMA followed by up to VALU_PER_MFMA vector instructions
+    auto interleave_hint = [&]() {
+        constexpr int VALU_PER_MFMA = (10 * TN + 2 + TM * TN - 1) / (TM * TN) + 1;
+#pragma unroll
+        for (int j = 0; j < TM * TN; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // decode / address VALU
+        }
+    };
+
+    uint4 afA[TM], bfA[TN], afB[TM], bfB[TN];
+    // one step; buf = kb % NBUF is a compile-time constant, q0/q1/q2 = weights of steps kb, kb+1, kb+2
+    auto step = [&](int kb, auto buf_c, uint64_t (&q0)[TN], uint64_t (&q1)[TN], uint64_t (&q2)[TN]) {
+        constexpr int buf = decltype(buf_c)::value;
+        constexpr int buf1 = (buf + 1) % NBUF, buf2 = (buf + 2) % NBUF;
+        // Each 16-deep sub-step: the 4 (TM) LDS reads of the NEXT sub-step's activation fragments go
+        // first (pinned by sched_barrier so they cannot sink to their use), then the 8 (TM*TN) MFMAs of
+        // the CURRENT sub-step are interleaved with the decode of the next weight fragments.
+        read_a(buf, 1, afB);
+        __builtin_amdgcn_sched_barrier(0);
+        decode_b(q0, 1, bfB); mma(afA, bfA);
+        interleave_hint();
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(buf, 2, afA);
+        __builtin_amdgcn_sched_barrier(0);
+        decode_b(q0, 2, bfA); mma(afB, bfB);
+        interleave_hint();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- middle of the step: tile kb+1 (and its weights q1) complete, tile kb-1 retired ----
+        wait_loads(q1);
+        __builtin_amdgcn_s_barrier();
+        // branch-free tail: past the end the loads re-fetch the last tile into a buffer nobody reads
+        // again and the prefetched fragments are never used
+        const int kn = kb + 2 < nk ? kb + 2 : nk - 1;
+        read_a(buf, 3, afB);
+        stage_a(kn, buf2); load_b(kn, q2);
+        __builtin_amdgcn_sched_barrier(0);
+        decode_b(q0, 3, bfB); mma(afA, bfA);
+        interleave_hint();
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(buf1, 0, afA);
+        __builtin_amdgcn_sched_barrier(0);
+        decode_b(q1, 0, bfA); mma(afB, bfB);
+        interleave_hint();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     stage_a(0, 0);
+    load_b(0, bq0);
+    if (nk > 1) { stage_a(1, 1); load_b(1, bq1); }
+    else {
 #pragma unroll
-    for (int t = 0; t < TN; ++t) bq_next[t] = bq[t] = *reinterpret_cast<const uint2*>(b_src[t]);
-
-    for (int kb = 0; kb < nk; ++kb) {
-        // the tile for this step was issued one step ago; every wave drains its own LDS-DMA, then
-        // the barrier makes all pieces visible and retires the reads of the buffer refilled below
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kb + 1 < nk) {
-            stage_a(kb + 1, (kb + 1) & 1);
-#pragma unroll
-            for (int t = 0; t < TN; ++t) bq_next[t] = *reinterpret_cast<const uint2*>(b_src[t] + (int64_t)(kb + 1) * (BK / 4));
-        }
-        const unsigned char* abase = lds + (kb & 1) * A_TILE_BYTES + a_row_off;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            uint4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const uint4*>(abase + i * 32 * ROW_BYTES + a_col_off[s]);
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const uint32_t d = (s < 2) ? bq[t].x : bq[t].y;
-                bf[t] = (s & 1) ? decode8<TX, 1>(d) : decode8<TX, 0>(d);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int t = 0; t < TN; ++t) acc[i][t] = mfma32<TX>(af[i], bf[t], acc[i][t]);
-        }
-#pragma unroll
-        for (int t = 0; t < TN; ++t) bq[t] = bq_next[t];
+        for (int t = 0; t < TN; ++t) bq1[t] = 0;
     }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) bq2[t] = 0;
+    wait_loads(bq0);
+    wait_loads(bq1);
+    __builtin_amdgcn_s_barrier();
+    read_a(0, 0, afA);
+    decode_b(bq0, 0, bfA);
+    for (int kb = 0; kb < nk; kb += NBUF) {
+        step(kb, std::integral_constant<int, 0>{}, bq0, bq1, bq2);
+        if (kb + 1 < nk) step(kb + 1, std::integral_constant<int, 1>{}, bq1, bq2, bq0);
+        if (kb + 2 < nk) step(kb + 2, std::integral_constant<int, 2>{}, bq2, bq0, bq1);
+    }
+    // Drain before leaving the loop: no LDS-DMA may outlive the workgroup's LDS allocation, and the
+    // destination registers of the last (unused) weight loads must stay reserved until the data has
+    // landed - a register freed earlier could be reused and then overwritten by the late load.
+    wait_loads(bq0);
+    wait_loads(bq1);
+    wait_loads(bq2);
 
-    // ---- epilogue: lane owns column n = .. + r, rows (e&3) + 8 (e>>2) + 4 h ---------------------
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // The weights are the MFMA "A" operand, so a lane owns ONE activation row m = .. + r and, per
+    // accumulator register group q = e >> 2, four consecutive output channels n = .. + 8q + 4h + (e & 3).
+    // 16/32-bit outputs: one v_permlane32_swap per register pair hands lanes 0-31 the upper half-wave's
+    // channels of group q and lanes 32-63 the lower half-wave's channels of group q+1, so every lane
+    // stores 16 contiguous bytes (8x fewer store instructions than one element per lane).
     const float c = fabsf(clip);
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) | (uintptr_t)(ld_y * (int64_t)sizeof(TY))) & 15) == 0;
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
-        const int gn = n0 + wc * WN + t * 32 + r;
-        if (gn >= n) continue;
-        const float sc = scale[gn];
-        const float bi = HAS_BIAS ? bias[gn] : 0.0f;
+        const int nb = n0 + wc * WN + t * 32;  // first channel of this 32-wide tile
+        float sc[16], bi[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int gn = nb + (e & 3) + 8 * (e >> 2) + 4 * h;
+            sc[e] = gn < n ? scale[gn] : 0.0f;
+            bi[e] = (HAS_BIAS && gn < n) ? bias[gn] : 0.0f;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int gm = m0 + wr * WM + i * 32 + r;
+            float v[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int gm = m0 + wr * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (gm < m) y[(int64_t)gm * ld_y + gn] = from_float<TY>(epilogue<HAS_BIAS, ACT>(acc[i][t][e], sc, bi, c));
+            for (int e = 0; e < 16; ++e) v[e] = epilogue<HAS_BIAS, ACT>(acc[i][t][e], sc[e], bi[e], c);
+            TY* yrow = y + (int64_t)(gm < m ? gm : 0) * ld_y;
+            if (vec_ok && nb + 32 <= n) {
+                if (gm < m) {
+                    if constexpr (sizeof(TY) == 4) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<float4*>(yrow + nb + 8 * q + 4 * h) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    }
+                }
+                if constexpr (sizeof(TY) == 2) {
+                    // pack 4 channels -> 8 bytes per group, then swap halves between register pairs
+                    uint2 pk[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        TY tmp[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tmp[j] = from_float<TY>(v[4 * q + j]);
+                        pk[q] = *reinterpret_cast<const uint2*>(tmp);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        // all 64 lanes take part in the swap (no divergence above this point)
+                        auto sx = __builtin_amdgcn_permlane32_swap(pk[q].x, pk[q + 1].x, false, false);
+                        auto sy = __builtin_amdgcn_permlane32_swap(pk[q].y, pk[q + 1].y, false, false);
+                        // lanes 0-31: [own group q | upper half's group q]; lanes 32-63: [lower half's group q+1 | own q+1]
+                        const uint4 out = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                        if (gm < m) *reinterpret_cast<uint4*>(yrow + nb + 8 * q + 8 * h) = out;
+                    }
+                }
+            } else if (gm < m) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int gn = nb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (gn < n) yrow[gn] = from_float<TY>(v[e]);
+                }
             }
         }
     }
@@ -208,7 +358,7 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
                       const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
     const int tiles_m = (int)ceil_div(m, BM), tiles_n = (int)ceil_div(n, BN);
     const int nblk = tiles_m * tiles_n;
-    const size_t lds_bytes = 2 * BM * ROW_BYTES;
+    const size_t lds_bytes = (size_t)NBUF * BM * ROW_BYTES;
     const dim3 grid(nblk), block(64 * WAVES_M * WAVES_N);
 #define TVL_GM(HB, ACT)                                                                                            \
     do {                                                                                                           \
@@ -234,7 +384,7 @@ static int launch_mfma_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const
     // 256x256 tiles when they fill the chip (>= ~1 tile per CU), else smaller tiles
     const int64_t big_tiles = ceil_div(m, 256) * ceil_div(n, 256);
     if (big_tiles >= 192)
-        return launch_cfg<TX, TY, 256, 256, 2, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
+        return launch_cfg<TX, TY, 256, 256, 1, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
     if (m > 64)
         return launch_cfg<TX, TY, 128, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
     if (m > 32)
