@@ -1,0 +1,212 @@
+"""Weight transfer from the trainable torch layers to the packed inference layers, and the packed arena.
+
+Mirror of the ternary branches of ``transfer_dense_params_torch_to_tf`` (``utils/conversion.py:32-94``):
+``ternary_act(w) -> int8 -> pack -> set_weights([scale, bias, packed])`` with ``clip_val = maxval``.  Here the
+quantize and pack steps are one HIP kernel (``ternarize_pack``); nothing is computed on the host.
+
+The arena is this build's on-device / on-disk form of a converted checkpoint: every selected layer's packed
+weights in ONE contiguous uint8 buffer (rows padded to 16 bytes so each layer is directly usable by the
+matrix-core kernel), plus concatenated scales and biases and a small index.  It is what gets broadcast to
+the other GPUs when activations are sharded by rows (one collective for all layers).
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Mapping, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import custom_ops_mod as ops
+from .layers import (ScaledTernary, ScaledTernaryMatmul, ScaledTernaryPackedMM, ScaledTernaryTf, ScaledTernaryUnpack,
+                     gelu_tanh)
+from .modules import ScaledBinary01Linear, ScaledBinaryLinear, ScaledTernaryLinear, _ScaledQuantLinear
+
+VARIANTS = {"matmul": ScaledTernaryMatmul, "unpack": ScaledTernaryUnpack, "tf": ScaledTernaryTf,
+            "packedmm": ScaledTernaryPackedMM, "continuous": ScaledTernary}
+
+
+@torch.no_grad()
+def transfer_dense_params_torch_to_packed(dense_packed: nn.Module, dense_torch: _ScaledQuantLinear):
+    """``transfer_dense_params_torch_to_tf`` (``utils/conversion.py:32-94``) for the packed layer classes.
+    ``dense_packed`` must be built (``build((..., K))``)."""
+    assert isinstance(dense_torch, _ScaledQuantLinear), "expected a Scaled{Ternary,Binary,Binary01}Linear"
+    w, b, scale = dense_torch.weights.detach(), dense_torch.bias, dense_torch.scale.detach()
+    b = b.detach() if b is not None else torch.zeros_like(scale)
+    quant = dense_torch.quantization
+    dense_packed.clip_val = dense_torch.maxval  # conversion.py:39,56,75,90
+    if isinstance(dense_packed, ScaledTernary):
+        # conversion.py:41: latent weights transposed to the Keras kernel layout [K, units]
+        dense_packed.set_weights([scale, b, w.t().contiguous()])
+    elif isinstance(dense_packed, ScaledTernaryTf):
+        # conversion.py:52-58: quantize, flatten, planar pack
+        t = ops.quantize(w, quant, dtype=torch.int8)
+        dense_packed.set_weights([scale, b, dense_packed.pack_fn(t.reshape(-1))])
+    elif isinstance(dense_packed, ScaledTernaryMatmul):  # also Unpack and PackedMM (subclasses)
+        # conversion.py:71-77 / :87-92: quantize + row-interleaved pack, fused into one kernel
+        dense_packed.set_weights([scale, b, ops.ternarize_pack(w, 0.5, quant)])
+    else:
+        raise TypeError(f"unsupported packed layer type {type(dense_packed).__name__}")
+
+
+@torch.no_grad()
+def to_packed_inference(model: nn.Module, variant: str = "matmul", gelu_names: Iterable[str] = ("fc1",)) -> List[str]:
+    """Swap every ``Scaled*Linear`` in ``model`` for a packed inference layer of the given variant
+    (``torch_moondream_to_keras``, ``utils/conversion.py:175-196``): layers whose attribute name is in
+    ``gelu_names`` get the tanh-GELU activation like ``fc1`` (``:185-187``).  Note that the activation then
+    becomes part of the layer: remove it from the surrounding block.  Returns the converted names."""
+    if variant not in VARIANTS:
+        raise ValueError(f"Unknown variant: {variant}")
+    done = []
+    for parent_name, parent in list(model.named_modules()):
+        for name, mod in list(parent.named_children()):
+            if isinstance(mod, _ScaledQuantLinear):
+                act = gelu_tanh if name in set(gelu_names) else None
+                layer = VARIANTS[variant](mod.out_features, activation=act, clip_val=mod.maxval).to(mod.weights.device)
+                layer.build((1, mod.in_features))
+                transfer_dense_params_torch_to_packed(layer, mod)
+                parent.add_module(name, layer)
+                done.append(f"{parent_name}.{name}" if parent_name else name)
+    return done
+
+
+# ---------------------------------------------------------------------------------------------------
+# packed arena
+# ---------------------------------------------------------------------------------------------------
+
+ROW_ALIGN = 16  # bytes: keeps every layer's rows 16-byte aligned inside the arena
+
+
+@dataclass
+class ArenaEntry:
+    name: str
+    n: int
+    k: int
+    ld: int          # packed row length in bytes
+    offset: int      # byte offset of the layer's first packed row
+    vec_offset: int  # element offset into scales / biases
+    maxval: float
+    has_bias: bool
+    quantization: str
+
+
+class PackedArena:
+    """All packed layers of a model in one device buffer.  ``layer(name)`` returns views
+    ``(pw [N, ld] uint8, scale [N], bias [N] | None, maxval)`` ready for ``ternary_matmul``."""
+
+    def __init__(self, packed: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor, entries: List[ArenaEntry]):
+        self.packed, self.scales, self.biases = packed, scales, biases
+        self.entries = {e.name: e for e in entries}
+
+    # -- construction -------------------------------------------------------------------------
+    @classmethod
+    @torch.no_grad()
+    def from_layers(cls, layers: Mapping[str, Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], float, str]],
+                    device=None) -> "PackedArena":
+        """``layers``: name -> (latent weights [N,K], scale [N], bias [N] | None, maxval, quantization)."""
+        entries, off, voff = [], 0, 0
+        for name, (w, scale, bias, maxval, quant) in layers.items():
+            n, k = w.shape
+            ld = -(-ops.packed_row_bytes(k) // ROW_ALIGN) * ROW_ALIGN
+            entries.append(ArenaEntry(name, n, k, ld, off, voff, float(abs(maxval)), bias is not None, quant))
+            off += n * ld
+            voff += n
+        any_w = next(iter(layers.values()))[0]
+        device = device or any_w.device
+        packed = torch.full((off,), 0x55, dtype=torch.uint8, device=device)  # pad bytes = four zeros
+        scales = torch.empty((voff,), dtype=torch.float32, device=device)
+        biases = torch.zeros((voff,), dtype=torch.float32, device=device)
+        for e in entries:
+            w, scale, bias, _, quant = layers[e.name]
+            view = packed[e.offset:e.offset + e.n * e.ld].view(e.n, e.ld)
+            ops.ternarize_pack(w.to(device), 0.5, quant, out=view)
+            scales[e.vec_offset:e.vec_offset + e.n] = scale.to(device, torch.float32)
+            if bias is not None:
+                biases[e.vec_offset:e.vec_offset + e.n] = bias.to(device, torch.float32)
+        return cls(packed, scales, biases, entries)
+
+    @classmethod
+    def from_model(cls, model: nn.Module) -> "PackedArena":
+        layers = {}
+        for name, mod in model.named_modules():
+            if isinstance(mod, _ScaledQuantLinear):
+                layers[name] = (mod.weights.detach(), mod.scale.detach(), mod.bias.detach() if mod.bias is not None else None,
+                                mod.maxval, mod.quantization)
+        if not layers:
+            raise ValueError("model has no Scaled*Linear layers")
+        return cls.from_layers(layers)
+
+    @classmethod
+    def from_state_dict(cls, state: Mapping[str, torch.Tensor], device, quantization: str = "ternary", maxval: float = 100.0,
+                        select=None) -> "PackedArena":
+        """Build from a checkpoint written by the reference's training script: a layer is every prefix
+        that has ``<prefix>.weights`` and ``<prefix>.scale`` (parameter names of ``binary/modules.py:96-98``;
+        ``<prefix>.bias`` optional).  ``select(prefix) -> bool`` narrows the choice."""
+        layers = {}
+        for key in state:
+            if key.endswith(".weights"):
+                p = key[: -len(".weights")]
+                if p + ".scale" in state and (select is None or select(p)):
+                    layers[p] = (state[key].to(device), state[p + ".scale"].to(device),
+                                 state[p + ".bias"].to(device) if p + ".bias" in state else None, maxval, quantization)
+        if not layers:
+            raise ValueError("no '<prefix>.weights' / '<prefix>.scale' pairs found in the state dict")
+        return cls.from_layers(layers, device)
+
+    # -- use -------------------------------------------------------------------------------------
+    def layer(self, name: str):
+        e = self.entries[name]
+        pw = self.packed[e.offset:e.offset + e.n * e.ld].view(e.n, e.ld)
+        scale = self.scales[e.vec_offset:e.vec_offset + e.n]
+        bias = self.biases[e.vec_offset:e.vec_offset + e.n] if e.has_bias else None
+        return pw, scale, bias, e.maxval
+
+    def matmul(self, name: str, x: torch.Tensor, activation=None, out_dtype=None) -> torch.Tensor:
+        e = self.entries[name]
+        if x.shape[-1] != e.k:
+            raise ValueError(f"layer {name} expects K={e.k}, got {x.shape[-1]}")
+        pw, scale, bias, maxval = self.layer(name)
+        return ops.ternary_matmul(x, pw, scale, bias, maxval, activation=activation, out_dtype=out_dtype)
+
+    def nbytes(self) -> int:
+        return self.packed.numel() + 4 * (self.scales.numel() + self.biases.numel())
+
+    # -- disk --------------------------------------------------------------------------------------
+    def save(self, path: str):
+        from safetensors.torch import save_file
+        meta = {"index": json.dumps([e.__dict__ for e in self.entries.values()]), "format": "ternary-packed-arena-v1"}
+        save_file({"packed": self.packed.cpu(), "scales": self.scales.cpu(), "biases": self.biases.cpu()}, path, metadata=meta)
+
+    @classmethod
+    def load(cls, path: str, device) -> "PackedArena":
+        from safetensors import safe_open
+        with safe_open(path, framework="pt", device="cpu") as f:
+            meta = f.metadata()
+            if meta.get("format") != "ternary-packed-arena-v1":
+                raise ValueError(f"{path} is not a packed arena")
+            entries = [ArenaEntry(**d) for d in json.loads(meta["index"])]
+            return cls(f.get_tensor("packed").to(device), f.get_tensor("scales").to(device), f.get_tensor("biases").to(device), entries)
+
+    # -- multi-GPU ---------------------------------------------------------------------------------
+    def broadcast(self, src: int = 0, group=None):
+        """Replicate the arena from rank ``src`` to every rank (three collectives for ALL layers; RCCL
+        when the tensors are on GPUs).  Every rank must hold an arena with the same index."""
+        import torch.distributed as dist
+        for t in (self.packed, self.scales, self.biases):
+            dist.broadcast(t, src=src, group=group)
+
+    @classmethod
+    def empty_like_index(cls, entries: List[ArenaEntry], device) -> "PackedArena":
+        total = max((e.offset + e.n * e.ld for e in entries), default=0)
+        nvec = max((e.vec_offset + e.n for e in entries), default=0)
+        return cls(torch.empty((total,), dtype=torch.uint8, device=device), torch.empty((nvec,), dtype=torch.float32, device=device),
+                   torch.empty((nvec,), dtype=torch.float32, device=device), entries)
+
+
+def shard_rows(m: int, world: int, rank: int) -> Tuple[int, int]:
+    """Row range ``[begin, end)`` of rank ``rank`` when ``m`` activation rows are split as evenly as
+    possible over ``world`` ranks (first ``m % world`` ranks get one row more)."""
+    base, rem = divmod(m, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)

@@ -1,0 +1,158 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol of include/tvl.h, argument errors
+are reported without a GPU, the host-side helpers, and the row-sharded multi-rank path over gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ternary_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ternary_vllm_amd as tv
+    header = open(os.path.join(ROOT, "include", "tvl.h")).read()
+    declared = set(re.findall(r"\b(tvl_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found in include/tvl.h"
+    lib = ctypes.CDLL(tv.custom_ops_mod.LIBRARY_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in tvl.h but not exported"
+    assert declared == set(tv.custom_ops_mod.SIGNATURES), "python binding table and header disagree"
+    assert tv.custom_ops_mod.library_version() == 100
+    out = subprocess.check_output(["nm", "-D", "--defined-only", tv.custom_ops_mod.LIBRARY_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert exported == declared, f"unexpected exported symbols: {exported ^ declared}"
+
+
+def test_argument_errors_without_gpu():
+    """Validation happens before any launch: bad arguments give TVL_ERR_INVALID and a message."""
+    import ternary_vllm_amd as tv
+    lib = tv.custom_ops_mod._lib
+    rc = lib.tvl_ternary_matmul(None, 9, 4, 64, 0, None, 8, 0, None, None, 1.0, 0, None, 0, 0, None, 0, None)
+    assert rc == 1 and b"dtype" in lib.tvl_last_error()
+    rc = lib.tvl_ternary_matmul(None, 1, 4, 64, 0, None, 8, 15, None, None, 1.0, 0, None, 1, 0, None, 0, None)
+    assert rc == 1 and b"packed rows hold 15 bytes" in lib.tvl_last_error()
+    rc = lib.tvl_ternary_matmul(None, 1, 4, 64, 0, None, 8, 0, None, None, 1.0, 0, None, 1, 0, None, 0, None)
+    assert rc == 1 and b"NULL" in lib.tvl_last_error()
+    assert lib.tvl_ternary_matmul(None, 1, 0, 64, 0, None, 8, 0, None, None, 1.0, 0, None, 1, 0, None, 0, None) == 0  # m = 0
+    assert lib.tvl_unpack(None, 4, 65, 16, None, 0, 0, None) == 1
+    assert lib.tvl_quantize_pack(None, 0, 4, 8, 0, 7, 0.5, None, 0, None) == 1 and b"quantizer" in lib.tvl_last_error()
+    assert lib.tvl_pack_planar_i8(None, 8, 5, None, None) == 1
+    with pytest.raises(ValueError):
+        tv.ternary_matmul(torch.zeros(2, 8), torch.zeros(2, 2, dtype=torch.uint8), torch.ones(2), None, 1.0)  # CPU tensors
+    with pytest.raises(ValueError):
+        tv.pack_fn(torch.zeros(2, 8, dtype=torch.int8))
+
+
+def test_row_bytes_and_sharding_helpers():
+    import ternary_vllm_amd as tv
+    ops = tv.custom_ops_mod
+    for k in range(1, 40):
+        assert ops.packed_row_bytes(k) == O.packed_row_bytes(k)
+        assert ops.reference_row_bytes(k) == O.reference_row_bytes(k) >= ops.packed_row_bytes(k)
+    for m in (0, 1, 7, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            spans = [tv.shard_rows(m, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == m
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert tv.utils.layers_to_skip(24, 1, 1) == ["transformer.h.0.", "transformer.h.23."]  # convert.py:72
+
+
+def test_c_port_matches_numpy_oracle():
+    """The C/OpenMP restatement (CPU baseline of the benchmark) against the numpy oracle."""
+    from __graft_entry__ import build_oracle
+    lib = ctypes.CDLL(build_oracle())
+    rng = np.random.default_rng(5)
+    m, n, k = 37, 50, 203
+    x = (rng.integers(-64, 65, (m, k)) / 64.0).astype(np.float32)
+    w = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    pw = np.zeros((n, (k + 3) // 4), np.uint8)
+    lib.tvo_ternarize_pack_f32(w.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n), ctypes.c_int64(k), ctypes.c_float(0.5),
+                               pw.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(pw, O.pack_format_c(O.ternarize(w)))
+    scale = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    bias = rng.normal(size=n).astype(np.float32)
+    want = O.ternary_matmul(x, pw, scale, bias, 3.0)
+    for fn in (lib.tvo_ternary_matmul_dense_f32, lib.tvo_ternary_matmul_select_f32):
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_int]
+        y = np.empty((m, n), np.float32)
+        assert fn(x.ctypes.data, m, k, pw.ctypes.data, pw.shape[1], n, scale.ctypes.data, bias.ctypes.data, 3.0, y.ctypes.data, 2) == 0
+        assert np.array_equal(y, want)
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["TVL_ROOT"])
+import ternary_vllm_amd as tv
+from ternary_vllm_amd.conversion import ArenaEntry, PackedArena
+from oracle import ternary_oracle as O
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(7)                      # same on every rank: the full problem
+m, shapes = 11, {"fc1": (24, 16), "fc2": (16, 24)}
+x = (rng.integers(-64, 65, (m, 16)) / 64.0).astype(np.float32)
+entries, off, voff = [], 0, 0
+for name, (n, k) in shapes.items():
+    ld = 16
+    entries.append(ArenaEntry(name, n, k, ld, off, voff, 100.0, True, "ternary")); off += n * ld; voff += n
+arena = PackedArena.empty_like_index(entries, "cpu")
+full = {}
+if rank == 0:                                       # rank 0 owns the packed weights
+    arena.packed.fill_(0x55)
+    for e in entries:
+        w = rng.uniform(-1, 1, (e.n, e.k)).astype(np.float32)
+        pw = O.pack_format_c(O.ternarize(w))
+        arena.packed[e.offset:e.offset + e.n * e.ld].view(e.n, e.ld)[:, :pw.shape[1]] = torch.from_numpy(pw)
+        arena.scales[e.vec_offset:e.vec_offset + e.n] = torch.from_numpy(rng.uniform(0.5, 1.5, e.n).astype(np.float32))
+        arena.biases[e.vec_offset:e.vec_offset + e.n] = torch.from_numpy(rng.normal(size=e.n).astype(np.float32))
+else:
+    arena.packed.zero_(); arena.scales.zero_(); arena.biases.zero_()
+arena.broadcast(src=0)                              # one replication for all layers
+b, e_ = tv.shard_rows(m, world, rank)               # rows of x are independent: shard them, no collective
+def run(xx):
+    pw, s, bi, mv = arena.layer("fc1")
+    h = O.ternary_matmul(xx, pw.numpy(), s.numpy(), bi.numpy(), mv, k=16)
+    pw, s, bi, mv = arena.layer("fc2")
+    return O.ternary_matmul(h, pw.numpy(), s.numpy(), bi.numpy(), mv, k=24)
+mine = torch.from_numpy(run(x[b:e_]))
+sizes = [tv.shard_rows(m, world, r) for r in range(world)]
+parts = [torch.empty((hi - lo, 16), dtype=torch.float32) for lo, hi in sizes]
+dist.all_gather(parts, mine) if len({p.shape for p in parts}) == 1 else None
+gathered = [None] * world
+dist.all_gather_object(gathered, mine.numpy())
+got = np.concatenate(gathered, axis=0)
+want_all = [None]
+if rank == 0:
+    want_all = [run(x)]
+dist.broadcast_object_list(want_all, src=0)
+assert got.shape == (m, 16) and np.array_equal(got, want_all[0]), "sharded result differs from the unsharded one"
+dist.barrier()
+if rank == 0:
+    print("SHARD_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_row_sharded_two_ranks_gloo(tmp_path):
+    """world_size 2 over gloo on the CPU: arena broadcast from rank 0, rows of x sharded, outputs reassembled
+    equal to the single-rank result.  The oracle stands in for the GPU kernels (compute is not under test)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, TVL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29611", str(script)], env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "SHARD_OK" in out.stdout

@@ -1,0 +1,225 @@
+"""The host-side mirrors of the reference's layer classes, on the GPU, against the golden outputs of the
+reference's own torch layers and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from oracle import ternary_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tv():
+    import ternary_vllm_amd
+    return ternary_vllm_amd
+
+
+def _load(layer, g, tag, dev, bias=True):
+    with torch.no_grad():
+        layer.weights.copy_(torch.from_numpy(g[f"{tag}_w"]))
+        layer.scale.copy_(torch.from_numpy(g[f"{tag}_scale"]))
+        if bias:
+            layer.bias.copy_(torch.from_numpy(g[f"{tag}_b"]))
+    return layer.to(dev)
+
+
+@pytest.mark.parametrize("quant,cls", [("ternary", "ScaledTernaryLinear"), ("binary", "ScaledBinaryLinear"), ("binary01", "ScaledBinary01Linear")])
+@pytest.mark.parametrize("bias", [True, False])
+def test_scaled_linear_forward_matches_reference_golden(tv, dev, golden_dir, quant, cls, bias):
+    g = np.load(os.path.join(golden_dir, "scaled_linear_forward.npz"))
+    tag = f"{quant}_{'bias' if bias else 'nobias'}"
+    n, k = g[f"{tag}_w"].shape
+    layer = _load(getattr(tv, cls)(k, n, bias=bias, max_val=-float(g[f"{tag}_maxval"])), g, tag, dev, bias)  # abs(max_val)
+    assert layer.maxval == float(g[f"{tag}_maxval"])
+    assert sorted(n_ for n_, _ in layer.named_parameters()) == (["bias", "scale", "weights"] if bias else ["scale", "weights"])
+    x = torch.from_numpy(g[f"{tag}_x"]).to(dev)
+    with torch.no_grad():
+        y = layer(x)
+    assert np.array_equal(y.cpu().numpy(), g[f"{tag}_y"])       # bit-equal to the reference forward
+    y3 = layer.eval()(x.reshape(1, *x.shape).half())             # leading dims and f16 activations
+    assert y3.shape == (1, x.shape[0], n) and y3.dtype == torch.float16
+    assert torch.equal(y3[0].cpu(), torch.from_numpy(g[f"{tag}_y"]).half())
+
+
+def test_repack_follows_weight_updates(tv, dev):
+    torch.manual_seed(0)
+    layer = tv.ScaledTernaryLinear(64, 32).to(dev)
+    x = (torch.randint(-64, 65, (8, 64)).float() / 64).to(dev)
+    with torch.no_grad():
+        y0 = layer(x)
+        pw0 = layer.packed_weights()
+        assert layer.packed_weights() is pw0            # cached while the weights are unchanged
+        layer.weights.mul_(-1.0)                        # in-place update bumps the version
+        y1 = layer(x)
+        b = layer.bias
+        assert torch.equal(((y1 - b) + (y0 - b)).abs() < 1e-5, torch.ones_like(y0, dtype=torch.bool))  # sign flip
+    sd = layer.state_dict()
+    assert set(sd) == {"weights", "bias", "scale"}      # checkpoint names of binary/modules.py:96-98
+
+
+def test_training_forward_backward(tv, dev):
+    """The layers stay trainable (straight-through estimator); gradients against a dense torch model."""
+    torch.manual_seed(1)
+    layer = tv.ScaledTernaryLinear(48, 24).to(dev).train()
+    x = torch.randn(10, 48, device=dev, requires_grad=True)
+    y = layer(x)
+    y.square().sum().backward()
+    q = ((layer.weights >= 0.5).float() - (layer.weights <= -0.5).float()).detach()
+    x2 = x.detach().clone().requires_grad_(True)
+    wl = layer.weights.detach().clone().requires_grad_(True)
+    s2 = layer.scale.detach().clone().requires_grad_(True)
+    b2 = layer.bias.detach().clone().requires_grad_(True)
+    y2 = (nn.functional.linear(x2, q + wl - wl.detach()) * s2 + b2).clip(-100, 100)
+    y2.square().sum().backward()
+    assert torch.allclose(y, y2, atol=1e-4)
+    for a, b in ((x.grad, x2.grad), (layer.weights.grad, wl.grad), (layer.scale.grad, s2.grad), (layer.bias.grad, b2.grad)):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-3)
+
+
+def test_quantizer_functions(tv, dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "quantizers.npz"))
+    x = torch.from_numpy(g["x_grid"]).to(dev)
+    m = tv.modules
+    assert np.array_equal(m.tri_step_ste(x).cpu().numpy(), g["ternary_grid"])      # works without requires_grad too
+    xr = x.clone().requires_grad_(True)
+    out = m.tri_step_ste(xr)
+    out.sum().backward()
+    assert torch.equal(xr.grad, torch.ones_like(xr))                               # straight-through
+    assert np.array_equal(m.sign_ste(x).cpu().numpy(), g["sign_grid"])
+    assert np.array_equal(m.step_ste(x).cpu().numpy(), g["step_grid"])
+    xs = (x * 2).clone().requires_grad_(True)
+    m.sign_ste_sat(xs).sum().backward()
+    assert torch.equal(xs.grad, ((xs >= -1) & (xs <= 1)).float())
+
+
+def test_linear_to_quantized_matches_reference_golden(tv, dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "linear_to_quantized.npz"))
+    for key in g.files:
+        if not key.endswith("__scale"):
+            continue
+        quant, ns, sc = key.split("__")[:3]
+        try:
+            sc = float(sc)
+        except ValueError:
+            pass
+        holder = nn.Sequential(nn.Linear(96, 40)).to(dev)
+        with torch.no_grad():
+            holder[0].weight.copy_(torch.from_numpy(g["w"]))
+            holder[0].bias.copy_(torch.from_numpy(g["b"]))
+        assert tv.linear_to_quantized(holder, quantization=quant, scaling=sc, neuron_scale=ns)
+        q = holder[0]
+        assert type(q).__name__ == {"ternary": "ScaledTernaryLinear", "binary": "ScaledBinaryLinear", "binary01": "ScaledBinary01Linear"}[quant]
+        np.testing.assert_allclose(q.scale.detach().cpu().numpy(), g[key], rtol=1e-5, err_msg=key)
+        np.testing.assert_allclose(q.weights.detach().cpu().numpy(), g[key.replace("__scale", "__latent")], rtol=1e-5, atol=1e-6, err_msg=key)
+        assert np.array_equal(q.bias.detach().cpu().numpy(), g[key.replace("__scale", "__bias")])
+    holder = nn.Sequential(nn.Linear(8, 4)).to(dev)
+    with pytest.raises(ValueError):
+        tv.linear_to_quantized(holder, quantization="binary", neuron_scale="none")     # modules.py:211-212
+    with pytest.raises(ValueError):
+        tv.linear_to_quantized(holder, quantization="binary", scaling="bogus")         # modules.py:223-224
+    assert tv.linear_to_quantized(holder, quantization="ternary", neuron_scale="none")  # accepted, per row (convert.py:72-73)
+    assert not tv.linear_to_quantized(nn.Sequential(nn.ReLU()), quantization="ternary")
+
+
+class _Block(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.mixer = nn.Module()
+        self.mixer.Wqkv = nn.Linear(d, 3 * d)
+        self.mixer.out_proj = nn.Linear(d, d)
+        self.mlp = nn.Module()
+        self.mlp.fc1 = nn.Linear(d, 4 * d)
+        self.mlp.fc2 = nn.Linear(4 * d, d)
+
+
+class _Phi(nn.Module):
+    def __init__(self, d=64, n=4):
+        super().__init__()
+        self.transformer = nn.Module()
+        self.transformer.h = nn.ModuleList([_Block(d) for _ in range(n)])
+        self.lm_head = nn.Module()
+        self.lm_head.linear = nn.Linear(d, 100)
+
+
+def test_quantize_text_model_selection_rule(tv, dev):
+    """binary/utils.py:14-21: skip the first start_skip and last last_skip blocks and lm_head."""
+    phi = _Phi().to(dev)
+    names = tv.utils.quantize_text_model(phi, start_skip=1, last_skip=1, quantization="ternary", neuron_scale="independent")
+    assert sorted(names) == sorted([f"transformer.h.{i}.{p}" for i in (1, 2) for p in ("mixer", "mlp")])
+    assert isinstance(phi.transformer.h[0].mlp.fc1, nn.Linear) and isinstance(phi.transformer.h[3].mlp.fc1, nn.Linear)
+    assert isinstance(phi.transformer.h[1].mlp.fc1, tv.ScaledTernaryLinear) and isinstance(phi.lm_head.linear, nn.Linear)
+    tv.utils.clip_binary_weights(phi)
+    assert float(phi.transformer.h[1].mlp.fc1.weights.detach().abs().max()) <= 1.0
+    bits = tv.utils.quantized_size_bits(phi)
+    dense = sum(16 * p.numel() for b in (0, 3) for p in phi.transformer.h[b].parameters()) + 16 * (64 * 100 + 100)
+    tern = sum(2 * m.weights.numel() + 32 * m.bias.numel() for b in (1, 2) for m in phi.transformer.h[b].modules()
+               if isinstance(m, tv.ScaledTernaryLinear))
+    assert bits == dense + tern                                  # binary/utils.py:50-55
+
+
+@pytest.mark.parametrize("variant", ["matmul", "unpack", "tf", "packedmm", "continuous"])
+@pytest.mark.parametrize("k", [64, 52])
+def test_packed_layer_variants_agree(tv, dev, variant, k):
+    """Every storage variant of impl/tf/moondream/ternary.py computes the same function of the same torch layer."""
+    rng = np.random.default_rng(k)
+    n, m = 40, 9
+    src = tv.ScaledTernaryLinear(k, n, max_val=3.0).to(dev)
+    with torch.no_grad():
+        src.weights.copy_(torch.from_numpy(rng.uniform(-1, 1, (n, k)).astype(np.float32)))
+        src.scale.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, (n,)).astype(np.float32)))
+    x = torch.from_numpy(rng.integers(-64, 65, (2, m, k)).astype(np.float32) / 64).to(dev)
+    layer = tv.conversion.VARIANTS[variant](n, activation=None, clip_val=100.0).to(dev)
+    layer(x)                                              # builds with random packed bytes, like Keras
+    tv.conversion.transfer_dense_params_torch_to_packed(layer, src)
+    assert layer.clip_val == 3.0
+    with torch.no_grad():
+        want = src(x)
+        got = layer(x)
+    assert torch.equal(got, want)
+    want_np = O.scaled_linear_forward(x.cpu().numpy(), src.weights.detach().cpu().numpy(), src.scale.detach().cpu().numpy(),
+                                      src.bias.detach().cpu().numpy(), 3.0)
+    assert np.array_equal(got.cpu().numpy(), want_np)
+    w = layer.get_weights()
+    assert len(w) == 3 and w[0].shape == (n,) and w[1].shape == (n,)     # [scale, bias, packed | kernel]
+    if variant in ("matmul", "unpack", "packedmm"):
+        assert w[2].shape == (n, (k + 3) // 4) and w[2].dtype == torch.uint8
+    # fused vs unfused activation
+    layer.act = tv.layers.gelu_tanh
+    with torch.no_grad():
+        ga = layer(x)
+    assert torch.allclose(ga, nn.functional.gelu(want, approximate="tanh"), atol=2e-6)
+
+
+def test_to_packed_inference_and_arena(tv, dev, tmp_path):
+    torch.manual_seed(3)
+    phi = _Phi(d=64, n=3).to(dev)
+    tv.utils.quantize_text_model(phi, start_skip=0, last_skip=0, quantization="ternary", neuron_scale="independent")
+    x = (torch.randint(-64, 65, (5, 64)).float() / 64).to(dev)
+    blk = phi.transformer.h[1]
+    with torch.no_grad():
+        want_fc1 = blk.mlp.fc1(x)
+        want_qkv = blk.mixer.Wqkv(x)
+    arena = tv.PackedArena.from_model(phi)
+    assert set(arena.entries) == {f"transformer.h.{i}.{p}" for i in range(3) for p in ("mixer.Wqkv", "mixer.out_proj", "mlp.fc1", "mlp.fc2")}
+    assert torch.equal(arena.matmul("transformer.h.1.mlp.fc1", x), want_fc1)
+    assert torch.equal(arena.matmul("transformer.h.1.mixer.Wqkv", x.half(), out_dtype=torch.float32), want_qkv)
+    assert arena.packed.numel() == sum(e.n * e.ld for e in arena.entries.values())
+    # disk round trip (safetensors, no pickle)
+    path = str(tmp_path / "arena.safetensors")
+    arena.save(path)
+    back = tv.PackedArena.load(path, dev)
+    assert torch.equal(back.packed, arena.packed) and torch.equal(back.scales, arena.scales)
+    assert torch.equal(back.matmul("transformer.h.1.mlp.fc1", x), want_fc1)
+    # from a reference-style state dict (names ...weights / ...scale / ...bias)
+    sd = {k_: v.detach().cpu() for k_, v in phi.state_dict().items()}
+    arena2 = tv.PackedArena.from_state_dict(sd, dev, select=lambda p: "lm_head" not in p)
+    assert torch.equal(arena2.packed, arena.packed)
+    names = tv.conversion.to_packed_inference(phi, "matmul")
+    assert len(names) == 12 and isinstance(blk.mlp.fc1, tv.layers.ScaledTernaryMatmul)
+    with torch.no_grad():
+        assert torch.allclose(blk.mlp.fc1(x), nn.functional.gelu(want_fc1, approximate="tanh"), atol=2e-6)  # fc1 carries the GELU
+        assert torch.equal(blk.mixer.Wqkv(x), want_qkv)
