@@ -103,11 +103,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return start + i;
 }
 
-template <typename TX, typename TY, int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_BIAS, int ACT>
+// SPLIT = true: blockIdx.y selects a range of k steps; the raw float32 partial sums of that range go
+// to slab blockIdx.y of `y` (float [splits][m][ld_y]) and splitk_reduce_kernel finishes the job.
+template <typename TX, typename TY, int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_BIAS, int ACT, bool SPLIT>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
 gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
                  const float* __restrict__ scale, const float* __restrict__ bias, float clip, TY* __restrict__ y,
-                 int64_t ld_y, int tiles_n, int nblk) {
+                 int64_t ld_y, int tiles_n, int nblk, int steps_per_split) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;            // 32x32 MFMA tiles per wave
@@ -133,6 +135,14 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
         gm = gm < m ? gm : m - 1;
         a_src[i] = x + (int64_t)gm * ld_x + chunk * 8;
     }
+    const int total_steps = k / BK;
+    const int kb0 = SPLIT ? (int)blockIdx.y * steps_per_split : 0;   // first k step of this block
+    const int nk = SPLIT ? (total_steps - kb0 < steps_per_split ? total_steps - kb0 : steps_per_split) : total_steps;
+    if constexpr (SPLIT) {
+        y += (int64_t)blockIdx.y * m * ld_y;
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) a_src[i] += (int64_t)kb0 * BK;
+    }
     // LDS-DMA issued from inline asm: hipcc then neither counts it nor orders the fragment reads of
     // the OTHER buffer behind it (with the builtin it drains vmcnt(0) before the first ds_read of every
     // step, which serialises load and compute).  Completion is waited for by hand: every wave's
@@ -155,7 +165,7 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
     for (int t = 0; t < TN; ++t) {
         int gn = n0 + wc * WN + t * 32 + r;
         gn = gn < n ? gn : n - 1;
-        b_src[t] = pw + (int64_t)gn * ld_pw + 8 * h;
+        b_src[t] = pw + (int64_t)gn * ld_pw + 8 * h + (int64_t)kb0 * (BK / 4);
     }
 
     // ---- fragment read offsets -----------------------------------------------------------------
@@ -173,7 +183,6 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.0f;
 
-    const int nk = k / BK;
     const DecodeConsts dc = make_decode_consts();
 
     // Pipeline (NBUF = 3 LDS tiles): at the middle of step kb every wave waits for its own pieces of
@@ -304,15 +313,15 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int gn = nb + (e & 3) + 8 * (e >> 2) + 4 * h;
-            sc[e] = gn < n ? scale[gn] : 0.0f;
-            bi[e] = (HAS_BIAS && gn < n) ? bias[gn] : 0.0f;
+            sc[e] = (!SPLIT && gn < n) ? scale[gn] : 0.0f;
+            bi[e] = (!SPLIT && HAS_BIAS && gn < n) ? bias[gn] : 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int gm = m0 + wr * WM + i * 32 + r;
             float v[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = epilogue<HAS_BIAS, ACT>(acc[i][t][e], sc[e], bi[e], c);
+            for (int e = 0; e < 16; ++e) v[e] = SPLIT ? acc[i][t][e] : epilogue<HAS_BIAS, ACT>(acc[i][t][e], sc[e], bi[e], c);
             TY* yrow = y + (int64_t)(gm < m ? gm : 0) * ld_y;
             if (vec_ok && nb + 32 <= n) {
                 if (gm < m) {
@@ -353,20 +362,66 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
     }
 }
 
+// Sum the split-K slabs in a fixed order (deterministic) and apply the fused epilogue.
+template <typename TY, bool HAS_BIAS, int ACT>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t m, int64_t n,
+                                                            const float* __restrict__ scale, const float* __restrict__ bias,
+                                                            float clip, TY* __restrict__ y, int64_t ld_y) {
+    const float c = fabsf(clip);
+    const int64_t total = m * n, stride = m * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / n, col = i - r * n;
+        float acc = 0.0f;
+        for (int s = 0; s < splits; ++s) acc += slab[s * stride + i];
+        y[r * ld_y + col] = from_float<TY>(epilogue<HAS_BIAS, ACT>(acc, scale[col], HAS_BIAS ? bias[col] : 0.0f, c));
+    }
+}
+
+template <typename TY>
+static int launch_reduce(const float* slab, int splits, int64_t m, int64_t n, const float* scale, const float* bias, float clip,
+                         int act, TY* y, int64_t ld_y, hipStream_t st) {
+    int64_t g = ceil_div(m * n, 256);
+    g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    const dim3 grid((unsigned)g), block(256);
+#define TVL_RD(HB, ACT) hipLaunchKernelGGL((splitk_reduce_kernel<TY, HB, ACT>), grid, block, 0, st, slab, splits, m, n, scale, bias, clip, y, ld_y)
+    if (bias) {
+        if (act == TVL_ACT_GELU_TANH) TVL_RD(true, TVL_ACT_GELU_TANH); else TVL_RD(true, TVL_ACT_NONE);
+    } else {
+        if (act == TVL_ACT_GELU_TANH) TVL_RD(false, TVL_ACT_GELU_TANH); else TVL_RD(false, TVL_ACT_NONE);
+    }
+#undef TVL_RD
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
 template <typename TX, typename TY, int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                      const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
+                      const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, int splits, float* slab,
+                      hipStream_t st) {
     const int tiles_m = (int)ceil_div(m, BM), tiles_n = (int)ceil_div(n, BN);
     const int nblk = tiles_m * tiles_n;
     const size_t lds_bytes = (size_t)NBUF * BM * ROW_BYTES;
-    const dim3 grid(nblk), block(64 * WAVES_M * WAVES_N);
+    const dim3 block(64 * WAVES_M * WAVES_N);
+    if (splits > 1) {
+        const int total_steps = (int)(k / BK);
+        const int steps_per_split = (int)ceil_div(total_steps, splits);
+        splits = (int)ceil_div(total_steps, steps_per_split);  // no empty split
+        auto kern = gemm_mfma_kernel<TX, float, BM, BN, WAVES_M, WAVES_N, false, TVL_ACT_NONE, true>;
+        if (lds_bytes > 48 * 1024)
+            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(kern, dim3(nblk, splits), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip,
+                           slab, n, tiles_n, nblk, steps_per_split);
+        TVL_LAUNCH_CHECK();
+        return launch_reduce<TY>(slab, splits, m, n, scale, bias, clip, act, y, ld_y, st);
+    }
+    const dim3 grid(nblk);
 #define TVL_GM(HB, ACT)                                                                                            \
     do {                                                                                                           \
-        auto kern = gemm_mfma_kernel<TX, TY, BM, BN, WAVES_M, WAVES_N, HB, ACT>;                                    \
+        auto kern = gemm_mfma_kernel<TX, TY, BM, BN, WAVES_M, WAVES_N, HB, ACT, false>;                             \
         if (lds_bytes > 48 * 1024)                                                                                 \
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, y, \
-                           ld_y, tiles_n, nblk);                                                                   \
+                           ld_y, tiles_n, nblk, 0);                                                                \
     } while (0)
     if (bias) {
         if (act == TVL_ACT_GELU_TANH) TVL_GM(true, TVL_ACT_GELU_TANH); else TVL_GM(true, TVL_ACT_NONE);
@@ -378,28 +433,62 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
     return TVL_OK;
 }
 
+// Tile shape and split-K factor.  256x256 tiles when they fill the chip; otherwise smaller tiles and, when
+// even those leave most of the 256 CUs idle, the k range is split over blockIdx.y so that about 2-4
+// workgroups per CU stream the packed weights concurrently.  The split factor is bounded so that the
+// float32 partial slabs (written once, read once) stay below the bytes of the packed weights themselves.
+struct GemmPlan { int bm, bn, splits; };
+static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_bytes) {
+    GemmPlan p;
+    if (ceil_div(m, 256) * ceil_div(n, 256) >= 192) { p.bm = 256; p.bn = 256; p.splits = 1; return p; }
+    p.bm = m > 64 ? 128 : (m > 32 ? 64 : 32);
+    p.bn = 128;
+    const int64_t tiles = ceil_div(m, p.bm) * ceil_div(n, p.bn);
+    const int64_t steps = k / BK;
+    int64_t s = 1;
+    if (tiles < 384) {
+        s = 768 / tiles;                                           // aim at ~3 workgroups per CU
+        const int64_t by_steps = steps / 2 > 0 ? steps / 2 : 1;    // at least two k steps per split
+        const int64_t by_bytes = k / (16 * m) > 0 ? k / (16 * m) : 1;  // slab bytes <= packed weight bytes
+        const int64_t by_ws = (int64_t)(workspace_bytes / ((size_t)m * n * sizeof(float)));
+        s = s < by_steps ? s : by_steps;
+        s = s < by_bytes ? s : by_bytes;
+        s = s < by_ws ? s : by_ws;
+        s = s < 1 ? 1 : (s > 64 ? 64 : s);
+    }
+    p.splits = (int)s;
+    return p;
+}
+
+size_t gemm_mfma_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+    const GemmPlan p = plan_gemm(m, n, k, (size_t)1 << 40);
+    return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
+}
+
 template <typename TX, typename TY>
 static int launch_mfma_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                          const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
-    // 256x256 tiles when they fill the chip (>= ~1 tile per CU), else smaller tiles
-    const int64_t big_tiles = ceil_div(m, 256) * ceil_div(n, 256);
-    if (big_tiles >= 192)
-        return launch_cfg<TX, TY, 256, 256, 1, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
-    if (m > 64)
-        return launch_cfg<TX, TY, 128, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
-    if (m > 32)
-        return launch_cfg<TX, TY, 64, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
-    return launch_cfg<TX, TY, 32, 128, 1, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
+                          const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, void* workspace,
+                          size_t workspace_bytes, hipStream_t st) {
+    const bool ws_ok = workspace != nullptr && aligned(workspace, 16);
+    const GemmPlan p = plan_gemm(m, n, k, ws_ok ? workspace_bytes : 0);
+    float* slab = (float*)workspace;
+    if (p.bm == 256)
+        return launch_cfg<TX, TY, 256, 256, 1, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, 1, slab, st);
+    if (p.bm == 128)
+        return launch_cfg<TX, TY, 128, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, st);
+    if (p.bm == 64)
+        return launch_cfg<TX, TY, 64, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, st);
+    return launch_cfg<TX, TY, 32, 128, 1, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, st);
 }
 
 template <typename TX>
 static int launch_mfma_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
                          const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y,
-                         hipStream_t st) {
+                         void* ws, size_t ws_bytes, hipStream_t st) {
     switch (y_dtype) {
-        case TVL_F32: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (float*)y, ld_y, st);
-        case TVL_F16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (f16*)y, ld_y, st);
-        case TVL_BF16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (bf16_t*)y, ld_y, st);
+        case TVL_F32: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (float*)y, ld_y, ws, ws_bytes, st);
+        case TVL_F16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (f16*)y, ld_y, ws, ws_bytes, st);
+        case TVL_BF16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (bf16_t*)y, ld_y, ws, ws_bytes, st);
         default: set_error("ternary_matmul: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
     }
 }
@@ -417,9 +506,10 @@ bool gemm_mfma_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64
 
 int launch_gemm_mfma(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
                      int64_t ld_pw, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype,
-                     int64_t ld_y, hipStream_t st) {
-    if (x_dtype == TVL_F16) return launch_mfma_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
-    return launch_mfma_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
+                     int64_t ld_y, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (x_dtype == TVL_F16)
+        return launch_mfma_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
+    return launch_mfma_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
 }
 
 }  // namespace tvl

@@ -99,14 +99,13 @@ int tvl_quantize(const void* w, int w_dtype, int64_t numel, int mode, float thre
 }
 
 size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k) {
-    (void)m; (void)n; (void)k;
-    return 0;  // no kernel of this version needs scratch memory
+    if (m <= 0 || n <= 0 || k <= 0 || k % 64 != 0) return 0;
+    return gemm_mfma_workspace_bytes(m, n, k);  // split-K partial sums for shapes that underfill the chip
 }
 
 int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
                        const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y,
                        void* workspace, size_t workspace_bytes, void* stream) {
-    (void)workspace; (void)workspace_bytes;
     TVL_REQUIRE(m >= 0 && n >= 0 && k >= 0, "ternary_matmul: negative shape m=%lld n=%lld k=%lld", (long long)m, (long long)n, (long long)k);
     TVL_REQUIRE(float_dtype(x_dtype), "ternary_matmul: activation dtype must be f32/f16/bf16, got %d", x_dtype);
     TVL_REQUIRE(float_dtype(y_dtype), "ternary_matmul: output dtype must be f32/f16/bf16, got %d", y_dtype);
@@ -127,7 +126,7 @@ int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t
                 "ternary_matmul: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     if (gemm_mfma_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
-        return launch_gemm_mfma(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
+        return launch_gemm_mfma(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     return launch_gemm_generic(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
 }
 

@@ -30,7 +30,8 @@ bool gemm_mfma_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64
                          int64_t ld_pw);
 int launch_gemm_mfma(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
                      int64_t ld_pw, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype,
-                     int64_t ld_y, hipStream_t st);
+                     int64_t ld_y, void* workspace, size_t workspace_bytes, hipStream_t st);
+size_t gemm_mfma_workspace_bytes(int64_t m, int64_t n, int64_t k);
 
 // fit_scale.hip
 size_t fit_workspace_bytes();

@@ -289,6 +289,23 @@ def _planar(fmt: str) -> int:
 
 _ACTS = {None: ACT_NONE, "none": ACT_NONE, "gelu_tanh": ACT_GELU_TANH, "gelu": ACT_GELU_TANH}
 
+# Split-K scratch memory, one grow-only buffer per (device, stream): calls on one stream are ordered, so
+# they can share it; calls on different streams must not.
+_matmul_workspaces = {}
+
+
+def _matmul_workspace(device: torch.device, stream: int, m: int, n: int, k: int):
+    need = int(_lib.tvl_ternary_matmul_workspace_bytes(m, n, k))
+    if need == 0:
+        return None, 0
+    key = (device.index, stream)
+    ws = _matmul_workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((need,), dtype=torch.uint8, device=device)
+        _matmul_workspaces[key] = ws
+    return ws.data_ptr(), ws.numel()
+
+
 
 def ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias: Optional[torch.Tensor], clip_val: float,
                    activation: Optional[str] = None, out_dtype: Optional[torch.dtype] = None,
@@ -321,10 +338,12 @@ def ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias:
         if y.shape[0] != m or y.data_ptr() != out.data_ptr():
             raise ValueError("ternary_matmul: `out` must be a contiguous [..., N] tensor matching x")
     with torch.cuda.device(x.device):
+        stream = _stream(x)
+        ws_ptr, ws_bytes = _matmul_workspace(x.device, stream, m, n, k)
         _check(_lib.tvl_ternary_matmul(x2.data_ptr(), _dt(x2, "ternary_matmul(x)"), m, k, _ld(x2), pw.data_ptr(), n, _ld(pw),
                                        scale.data_ptr(), bias.data_ptr() if bias is not None else None, float(clip_val),
-                                       _ACTS[activation], y.data_ptr(), _dt(y, "ternary_matmul(out)"), _ld(y), None, 0,
-                                       _stream(x)))
+                                       _ACTS[activation], y.data_ptr(), _dt(y, "ternary_matmul(out)"), _ld(y), ws_ptr, ws_bytes,
+                                       stream))
     return y.reshape(*lead, n) if out is None else out
 
 
