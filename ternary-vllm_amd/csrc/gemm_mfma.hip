@@ -362,7 +362,9 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
     }
 }
 
-// Sum the split-K slabs in a fixed order (deterministic) and apply the fused epilogue.
+// Sum the split-K slabs in a fixed order (deterministic: slab 0, 1, 2, ...) and apply the fused epilogue.
+// One thread per output element; the slab loads of 8 consecutive splits are issued together (they are
+// independent; a one-load-at-a-time loop would pay the memory latency `splits` times).
 template <typename TY, bool HAS_BIAS, int ACT>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t m, int64_t n,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
@@ -371,8 +373,17 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     const int64_t total = m * n, stride = m * n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / n, col = i - r * n;
+        const float* p = slab + i;
         float acc = 0.0f;
-        for (int s = 0; s < splits; ++s) acc += slab[s * stride + i];
+        int s = 0;
+        for (; s + 8 <= splits; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(s + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; s < splits; ++s) acc += p[(int64_t)s * stride];
         y[r * ld_y + col] = from_float<TY>(epilogue<HAS_BIAS, ACT>(acc, scale[col], HAS_BIAS ? bias[col] : 0.0f, c));
     }
 }
@@ -392,6 +403,16 @@ static int launch_reduce(const float* slab, int splits, int64_t m, int64_t n, co
 #undef TVL_RD
     TVL_LAUNCH_CHECK();
     return TVL_OK;
+}
+
+int launch_splitk_reduce(const float* slab, int splits, int64_t m, int64_t n, const float* scale, const float* bias, float clip,
+                         int act, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
+    switch (y_dtype) {
+        case TVL_F32: return launch_reduce<float>(slab, splits, m, n, scale, bias, clip, act, (float*)y, ld_y, st);
+        case TVL_F16: return launch_reduce<f16>(slab, splits, m, n, scale, bias, clip, act, (f16*)y, ld_y, st);
+        case TVL_BF16: return launch_reduce<bf16_t>(slab, splits, m, n, scale, bias, clip, act, (bf16_t*)y, ld_y, st);
+        default: set_error("splitk_reduce: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
+    }
 }
 
 template <typename TX, typename TY, int BM, int BN, int WAVES_M, int WAVES_N>

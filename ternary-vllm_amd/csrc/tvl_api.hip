@@ -100,7 +100,10 @@ int tvl_quantize(const void* w, int w_dtype, int64_t numel, int mode, float thre
 
 size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0 || k % 64 != 0) return 0;
-    return gemm_mfma_workspace_bytes(m, n, k);  // split-K partial sums for shapes that underfill the chip
+    // split-K partial sums for shapes that underfill the chip (the larger of the two kernels' wishes)
+    const size_t a = gemm_mfma_workspace_bytes(m, n, k);
+    const size_t b = (m <= 32 && k % 256 == 0) ? gemm_skinny_workspace_bytes(m, n, k) : 0;
+    return a > b ? a : b;
 }
 
 int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
@@ -125,6 +128,8 @@ int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t
     TVL_REQUIRE(aligned(x, dtype_size(x_dtype)) && aligned(y, dtype_size(y_dtype)) && aligned(scale, 4) && aligned(bias, 4),
                 "ternary_matmul: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (gemm_skinny_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
+        return launch_gemm_skinny(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     if (gemm_mfma_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
         return launch_gemm_mfma(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     return launch_gemm_generic(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);

@@ -190,7 +190,8 @@ def _case(rng, m, n, k, grid=True, bias=True):
 
 SHAPES = [(1, 1, 1), (1, 8, 4), (3, 5, 7), (17, 33, 30), (64, 64, 64), (65, 130, 100), (5, 48, 5031),  # generic kernel
           (1, 128, 64), (7, 100, 128), (32, 128, 256), (33, 64, 192), (64, 256, 512), (100, 300, 640),  # MFMA, small tiles
-          (129, 129, 64), (200, 512, 1024), (745, 2048, 2048)]
+          (129, 129, 64), (200, 512, 1024), (745, 2048, 2048),
+          (1, 128, 256), (1, 4096, 4096), (3, 200, 768), (16, 130, 512), (31, 6144, 2048), (32, 256, 1024), (8, 96, 3072)]  # few rows: streaming kernel
 
 
 @pytest.mark.parametrize("m,n,k", SHAPES)
