@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) copy_u8_kernel(const uint8_t* __restrict_
 static inline int grid_for(int64_t work_items, int per_block) {
     int64_t g = ceil_div(work_items, per_block);
     if (g < 1) g = 1;
-    if (g > 256 * 8) g = 256 * 8;  // 8 blocks per CU, grid-stride beyond
+    if (g > 256 * 8) g = 256 * 8;  // 8 blocks per CU, grid-stride beyond (16-64 per CU measured: no faster)
     return (int)g;
 }
 

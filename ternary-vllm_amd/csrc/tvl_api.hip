@@ -103,7 +103,9 @@ size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     // split-K partial sums for shapes that underfill the chip (the larger of the two kernels' wishes)
     const size_t a = gemm_mfma_workspace_bytes(m, n, k);
     const size_t b = (m <= 32 && k % 256 == 0) ? gemm_skinny_workspace_bytes(m, n, k) : 0;
-    return a > b ? a : b;
+    const size_t c = (m <= 16 && k % 256 == 0) ? gemm_stream_workspace_bytes(m, n, k) : 0;
+    const size_t ab = a > b ? a : b;
+    return ab > c ? ab : c;
 }
 
 int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
@@ -128,6 +130,8 @@ int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t
     TVL_REQUIRE(aligned(x, dtype_size(x_dtype)) && aligned(y, dtype_size(y_dtype)) && aligned(scale, 4) && aligned(bias, 4),
                 "ternary_matmul: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (gemm_stream_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
+        return launch_gemm_stream(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     if (gemm_skinny_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
         return launch_gemm_skinny(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     if (gemm_mfma_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))

@@ -102,4 +102,10 @@ __device__ __forceinline__ float epilogue(float acc, float scale, float bias, fl
     return y;
 }
 
+// the same with the bias / activation choice made at run time (kernels where the epilogue is a vanishing share)
+__device__ __forceinline__ float epilogue_rt(float acc, float scale, float bias, bool has_bias, int act, float clip) {
+    if (has_bias) return act == TVL_ACT_GELU_TANH ? epilogue<true, TVL_ACT_GELU_TANH>(acc, scale, bias, clip) : epilogue<true, TVL_ACT_NONE>(acc, scale, bias, clip);
+    return act == TVL_ACT_GELU_TANH ? epilogue<false, TVL_ACT_GELU_TANH>(acc, scale, bias, clip) : epilogue<false, TVL_ACT_NONE>(acc, scale, bias, clip);
+}
+
 }  // namespace tvl

@@ -42,6 +42,14 @@ int launch_gemm_skinny(const void* x, int x_dtype, int64_t m, int64_t k, int64_t
                        size_t workspace_bytes, hipStream_t st);
 size_t gemm_skinny_workspace_bytes(int64_t m, int64_t n, int64_t k);
 
+// gemm_stream.hip
+bool gemm_stream_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                           const void* workspace, size_t workspace_bytes);
+int launch_gemm_stream(const void* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                       const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, void* workspace,
+                       size_t workspace_bytes, hipStream_t st);
+size_t gemm_stream_workspace_bytes(int64_t m, int64_t n, int64_t k);
+
 // fit_scale.hip
 size_t fit_workspace_bytes();
 int launch_fit_ternary(const float* w, int64_t n, int64_t k, int64_t ld_w, int uniform, int iters, float* scale, float* latent,

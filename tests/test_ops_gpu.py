@@ -191,7 +191,8 @@ def _case(rng, m, n, k, grid=True, bias=True):
 SHAPES = [(1, 1, 1), (1, 8, 4), (3, 5, 7), (17, 33, 30), (64, 64, 64), (65, 130, 100), (5, 48, 5031),  # generic kernel
           (1, 128, 64), (7, 100, 128), (32, 128, 256), (33, 64, 192), (64, 256, 512), (100, 300, 640),  # MFMA, small tiles
           (129, 129, 64), (200, 512, 1024), (745, 2048, 2048),
-          (1, 128, 256), (1, 4096, 4096), (3, 200, 768), (16, 130, 512), (31, 6144, 2048), (32, 256, 1024), (8, 96, 3072)]  # few rows: streaming kernel
+          (1, 128, 256), (1, 4096, 4096), (3, 200, 768), (16, 130, 512), (31, 6144, 2048), (32, 256, 1024), (8, 96, 3072),  # few rows:
+          (2, 1000, 16384), (5, 129, 8192), (9, 64, 1280), (12, 520, 4352), (16, 2048, 8192), (1, 30, 32768)]        # streaming kernels
 
 
 @pytest.mark.parametrize("m,n,k", SHAPES)
@@ -244,6 +245,43 @@ def test_matmul_invalid_code_and_padding(ops, dev, k):
         assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("m,k", [(1, 256), (4, 1024), (13, 8192)])
+def test_matmul_few_rows_invalid_code_and_extremes(ops, dev, m, k):
+    """The few-row kernel feeds the raw 2-bit codes to the matrix cores as f16 subnormals: every code value
+    (3 included, decoding as +2) at every bit position, and activations at the ends of the f16 range."""
+    rng = np.random.default_rng(k + m)
+    n = 70
+    pw = rng.integers(0, 256, size=(n, k // 4)).astype(np.uint8)
+    scale = np.ones((n,), np.float32)
+    x = _grid(rng, (m, k))
+    x[0, :8] = [65504.0, -65504.0, 2.0 ** -24, -(2.0 ** -24), 2.0 ** -14, 1024.0, -0.5, 0.0]  # f16 max, min subnormal, min normal
+    want = O.ternary_matmul(x.astype(np.float64), pw, scale, None, 1e30, acc_dtype=np.float64)
+    got = ops.ternary_matmul(torch.from_numpy(x).to(dev).half(), torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev), None, 1e30,
+                             out_dtype=torch.float32)
+    # row 0 mixes 6.5e4 with 6e-8: float32 accumulation cannot be exact there, the other rows are
+    assert np.array_equal(got.cpu().numpy()[1:], want[1:].astype(np.float32))
+    assert np.max(np.abs(got.cpu().numpy()[0] - want[0]) / np.maximum(1.0, np.abs(want[0]))) <= 1e-2 * 65504 * 2.0 ** -10
+
+
+def test_matmul_few_rows_without_workspace(ops, dev):
+    """Through the raw C ABI with workspace = NULL: long k ranges need split-K scratch for the streaming kernel,
+    so the call must fall back to a kernel that needs none - same bits on the exact grid."""
+    import ctypes
+    rng = np.random.default_rng(5)
+    m, n, k = 3, 200, 16384 + 256
+    x, pw, scale, b = _case(rng, m, n, k)
+    want = O.ternary_matmul(x, pw, scale, b, 100.0)
+    xt, pwt = torch.from_numpy(x).to(dev).half(), torch.from_numpy(pw).to(dev)
+    st, bt = torch.from_numpy(scale).to(dev), torch.from_numpy(b).to(dev)
+    y = torch.empty((m, n), dtype=torch.float32, device=dev)
+    lib = ops._lib
+    rc = lib.tvl_ternary_matmul(xt.data_ptr(), ops.F16, m, k, 0, pwt.data_ptr(), n, 0, st.data_ptr(), bt.data_ptr(), ctypes.c_float(100.0),
+                                ops.ACT_NONE, y.data_ptr(), ops.F32, 0, None, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.tvl_last_error()
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), want)
+
+
 def test_matmul_strided_inputs(ops, dev):
     rng = np.random.default_rng(21)
     m, n, k = 70, 130, 128
@@ -262,7 +300,7 @@ def test_matmul_strided_inputs(ops, dev):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("m,n,k", [(16, 64, 96), (150, 256, 256), (64, 128, 4096)])
+@pytest.mark.parametrize("m,n,k", [(16, 64, 96), (150, 256, 256), (64, 128, 4096), (1, 256, 4096), (7, 192, 2048), (16, 128, 8192)])
 def test_matmul_randn_vs_f64(ops, dev, m, n, k):
     """N(0,1) activations: float32 accumulation against the float64 oracle.
 

@@ -1,8 +1,8 @@
-"""Audit a hipcc .s file: for every kernel, list compiler-inserted register copies (v_mov) whose SOURCE is the
-destination of an inline-asm global load.  Such a copy placed between the load and the hand-written
-s_waitcnt reads the register before the data has landed (the compiler does not know the load is still
-in flight).  Copies located after the wait are harmless; this tool prints all of them with line numbers
-and the position of the nearest preceding wait so they can be checked.
+"""Audit a hipcc .s file: for every kernel, list compiler-emitted instructions that READ a register which is
+the destination of an inline-asm global load still in flight.  hipcc does not know about such loads: a copy
+(or any use) it places between the load and the hand-written s_waitcnt sees the register before the data has
+landed.  Vector-memory operations are modelled as an in-order queue; s_waitcnt vmcnt(N) retires all but the
+N youngest.  The listing is walked twice so that loads still in flight at a loop's end reach its header.
 
     python tools/audit_asm_loads.py file.s [kernel-name-substring]
 """
@@ -34,8 +34,17 @@ for name in names:
         continue
     last_wait = None
     bad = []
-    state = {}  # reg -> line of the asm load that is still in flight; cleared by an asm wait
+    fifo = []   # vector-memory operations in issue order: the set of registers an inline-asm load will write (empty
+                # for LDS-DMA, stores and compiler-issued operations); s_waitcnt vmcnt(N) retires all but the N youngest
     in_asm = False
+
+    def in_flight():
+        regs = {}
+        for line_no, rs in fifo:
+            for r in rs:
+                regs[r] = line_no
+        return regs
+
     # two passes over the listing: the second one starts with whatever was still in flight at the end of the
     # first, which approximates values carried around a loop's back-edge to its header
     for i, l in [(i, l) for _ in range(2) for i, l in enumerate(lines)]:
@@ -45,20 +54,31 @@ for name in names:
         if "#ASMEND" in l:
             in_asm = False
             continue
-        if in_asm:
-            m = re.search(r"global_load_dwordx[24] v\[(\d+):(\d+)\]", l)
-            if m:
-                for r in range(int(m.group(1)), int(m.group(2)) + 1):
-                    state[r] = i
-            if "s_waitcnt vmcnt(0)" in l:
-                state.clear()
-                last_wait = i
+        mw = re.search(r"s_waitcnt .*vmcnt\((\d+)\)", l)
+        if mw:
+            n = int(mw.group(1))
+            fifo = fifo[len(fifo) - n:] if n else []
+            last_wait = i
             continue
-        m = re.match(r"\s*v_mov_b(?:32|64)_e32 \S+ v\[?(\d+)(?::(\d+))?\]?", l)
-        if m:
-            lo = int(m.group(1))
-            hi = int(m.group(2)) if m.group(2) else lo
-            hit = [r for r in range(lo, hi + 1) if r in state]
+        if re.match(r"\s*(global|buffer|flat|scratch)_(load|store|atomic)", l):
+            m = re.search(r"global_load_dwordx[24] v\[(\d+):(\d+)\]", l) if in_asm else None
+            fifo.append((i, set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()))
+            continue
+        if in_asm:
+            continue
+        # any instruction the compiler emitted that READS a register whose asm-issued load is still in flight
+        mi = re.match(r"\s*((?:v|ds|global|buffer|flat)_\w+)\s+(.*)", l)
+        if mi:
+            ops = [o.strip() for o in mi.group(2).split(",")]
+            srcs = ops if re.match(r"(ds_write|global_store|buffer_store|flat_store)", mi.group(1)) else ops[1:]
+            state = in_flight()
+            hit = []
+            for o in srcs:
+                for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", o):
+                    hit += [r for r in range(int(lo), int(hi) + 1) if r in state]
+                for r in re.findall(r"\bv(\d+)\b", o):
+                    if int(r) in state:
+                        hit.append(int(r))
             if hit:
                 if (i, l.strip()) not in [(b[0], b[1]) for b in bad]:
                     bad.append((i, l.strip(), "load at line %d still in flight" % state[hit[0]]))
