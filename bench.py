@@ -38,21 +38,53 @@ def gemm_bytes(m, n, k, out_bytes=2):
     return m * k * 2 + n * ((k + 3) // 4) + 2 * n * 4 + m * n * out_bytes
 
 
-def time_launches(fn, steps, warmup):
-    """Average device time of fn() in ms, measured with events on the current stream (the stream the
-    kernels are launched on)."""
-    for _ in range(warmup):
-        fn(0)
-    torch.cuda.synchronize()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-    for i in range(steps):
-        starts[i].record()
+def time_launches(fn, steps, warmup, rounds=5):
+    """Device time of one fn() in ms: one event pair around `steps` back-to-back launches on the current stream
+    (the stream the library launches on), repeated `rounds` times.  Returns (average, best round).  A pair per
+    launch would add the event markers' own few microseconds to every sample."""
+    for i in range(warmup):
         fn(i)
-        ends[i].record()
     torch.cuda.synchronize()
-    ts = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
-    return sum(ts) / len(ts), ts[len(ts) // 2]
+    per = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(steps):
+            fn(i)
+        b.record()
+        torch.cuda.synchronize()
+        per.append(a.elapsed_time(b) / steps)
+    return sum(per) / len(per), min(per)
+
+
+def time_graph(fn, launches, warmup, rounds=5):
+    """As time_launches, but the `launches` calls are captured into one HIP graph and the graph is replayed:
+    the device time of kernels that are shorter than the host's cost of launching them (a few-row matmul is
+    ~8 us of device time behind ~20 us of Python + ctypes per call).  Falls back to eager timing if the
+    capture fails."""
+    try:
+        for i in range(warmup):
+            fn(i)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(launches):
+                fn(i)
+        graph.replay()
+        torch.cuda.synchronize()
+        per = []
+        for _ in range(rounds):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            graph.replay()
+            b.record()
+            torch.cuda.synchronize()
+            per.append(a.elapsed_time(b) / launches)
+        return sum(per) / len(per), min(per), "hip graph replay"
+    except Exception as e:  # noqa: BLE001
+        torch.cuda.synchronize()
+        a, b = time_launches(fn, launches, warmup, rounds)
+        return a, b, f"eager launches (graph capture failed: {type(e).__name__})"
 
 
 def cpu_baseline(m_full, n, k, seed, budget_s=12.0):
@@ -115,8 +147,8 @@ def cpu_baseline(m_full, n, k, seed, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--k", type=int, default=4096)
@@ -168,18 +200,27 @@ def main():
     def step(i):
         ops.ternary_matmul(xs[i % nbuf], pw, scale, bias, 100.0, out=ys[i % nbuf])
 
+    # Set-up, untimed: bring the GPU out of its idle power state (the first milliseconds of matrix-core work
+    # after idling run at a lower clock), then the W warm-up steps the caller asked for.
+    PREWARM = 300
+    for i in range(PREWARM):
+        step(i)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(args.steps):
         step(i)
+    ev1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    event_ms_per_launch = ev0.elapsed_time(ev1) / args.steps   # device time of the timed region itself
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -191,14 +232,16 @@ def main():
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel, from per-launch device time (events on the launch stream)
-        avg_ms, med_ms = time_launches(step, max(20, min(args.steps, 100)), 5)
+        avg_ms = event_ms_per_launch
         flops = 2.0 * M * N * K
         achieved_tf = flops / (avg_ms * 1e-3) / 1e12
         by = gemm_bytes(M, N, K, 2)
+        big = (M + 255) // 256 * ((N + 255) // 256) >= 192
         roofline = {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved_tf / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
-                    "kernel": "gemm_mfma_kernel<f16,f16,256,256>", "avg_launch_ms": round(avg_ms, 4),
-                    "median_launch_ms": round(med_ms, 4), "flops_per_launch": flops}
+                    "kernel": "tvl::gemm_mfma_kernel<f16, f16, 256, 256, 1, 8, bias, none, no split>" if big else "tvl::gemm_mfma_kernel (small tiles / split-K)",
+                    "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops,
+                    "timing": f"one HIP event pair around the {args.steps} timed launches on the launch stream"}
         hbm = {"gemm_algorithmic_bytes": by, "gemm_GBps": round(by / (avg_ms * 1e-3) / 1e9, 1),
                "gemm_frac_of_hbm_peak": round(by / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "note": "4096^3 with f16 activations is matrix-core bound (1927 op/B): its HBM fraction is capped near 16 %"}
@@ -207,24 +250,44 @@ def main():
         nw = 6  # 6 x 64 MiB of latent weights > 256 MiB Infinity Cache
         wl = [torch.rand(N, K, device=dev) * 2 - 1 for _ in range(nw)]
         pws = [torch.empty_like(pw) for _ in range(nw)]
-        p_avg, p_med = time_launches(lambda i: ops.ternarize_pack(wl[i % nw], 0.5, out=pws[i % nw]), 30, 6)
+        p_avg, p_best = time_launches(lambda i: ops.ternarize_pack(wl[i % nw], 0.5, out=pws[i % nw]), 2 * nw, nw)
         pack_bytes = N * K * 4 + N * ((K + 3) // 4)
-        hbm["pack_kernel"] = {"algorithmic_bytes": pack_bytes, "avg_launch_ms": round(p_avg, 4),
+        hbm["pack_kernel"] = {"kernel": "tvl::quantize_pack_fast_kernel<float, ternary>", "shape": [N, K],
+                              "algorithmic_bytes": pack_bytes, "avg_launch_ms": round(p_avg, 4),
                               "GBps": round(pack_bytes / (p_avg * 1e-3) / 1e9, 1),
                               "frac_of_hbm_peak": round(pack_bytes / (p_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         del wl, pws
+        # ---- HBM-bound form of the matmul: one activation row (decode), weights streamed once from HBM.
+        # 16384 x 16384 (64 MiB packed, 10 rotating copies) is large enough to leave the launch-latency regime.
+        for (dn, dk, tag) in ((16384, 16384, "decode_m1_16384"), (N, K, "decode_m1")):
+            nd = max(2, min(40, (640 << 20) // (dn * dk // 4)))
+            pwd = [torch.randint(0, 171, (dn, dk // 4), dtype=torch.uint8, device=dev) for _ in range(nd)]
+            xd = torch.randn(1, dk, device=dev).half()
+            yd = torch.empty((1, dn), dtype=torch.float16, device=dev)
+            sd, bd = torch.ones(dn, device=dev), torch.zeros(dn, device=dev)
+            d_avg, d_best, how = time_graph(lambda i: ops.ternary_matmul(xd, pwd[i % nd], sd, bd, 100.0, out=yd), 2 * nd, nd)
+            d_bytes = gemm_bytes(1, dn, dk, 2)
+            hbm[tag] = {"kernel": "tvl::gemm_stream_kernel + tvl::splitk_reduce_kernel (2 launches)", "shape": [1, dn, dk], "timing": how,
+                        "algorithmic_bytes": d_bytes, "avg_call_ms": round(d_avg, 5), "GBps": round(d_bytes / (d_avg * 1e-3) / 1e9, 1),
+                        "frac_of_hbm_peak": round(d_bytes / (d_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del pwd
 
         if args.sweep:
             sweep = []
             shapes = [(mm, 4096, 4096) for mm in (1, 16, 64, 256, 1024, 4096)]
             shapes += [(mm, nn, kk) for mm in (1, 745) for (nn, kk) in ((6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192))]
+            shapes += [(128 * 197, nn, kk) for (nn, kk) in ((2304, 768), (768, 768), (3072, 768), (768, 3072))]   # ViT-Base/16, batch 128
             for (mm, nn, kk) in shapes:
                 nb = max(2, min(16, int(600e6 // max(1, nn * kk // 4 + mm * kk * 2))))  # rotate > 256 MiB where small
                 pwl = [torch.randint(0, 171, (nn, kk // 4), dtype=torch.uint8, device=dev) for _ in range(nb)]
                 xl = [torch.randn(mm, kk, device=dev).half() for _ in range(nb)]
                 yl = [torch.empty((mm, nn), dtype=torch.float16, device=dev) for _ in range(nb)]
                 sc = torch.ones(nn, device=dev); bi = torch.zeros(nn, device=dev)
-                a, md = time_launches(lambda i: ops.ternary_matmul(xl[i % nb], pwl[i % nb], sc, bi, 100.0, out=yl[i % nb]), 40, 8)
+                call = lambda i: ops.ternary_matmul(xl[i % nb], pwl[i % nb], sc, bi, 100.0, out=yl[i % nb])  # noqa: E731
+                if 2.0 * mm * nn * kk < 2e10:   # short kernels: device time through a graph, not host launch rate
+                    a, _, _ = time_graph(call, 2 * nb, nb)
+                else:
+                    a, _ = time_launches(call, max(2 * nb, 20), nb)
                 b_ = gemm_bytes(mm, nn, kk, 2)
                 sweep.append({"m": mm, "n": nn, "k": kk, "avg_ms": round(a, 5), "GOPS": round(2.0 * mm * nn * kk / (a * 1e-3) / 1e9, 1),
                               "GBps": round(b_ / (a * 1e-3) / 1e9, 1), "frac_hbm": round(b_ / (a * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -240,7 +303,7 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{M}x{N}x{K} ternary x f16 GEMM, 2-bit packed weights, fused scale/bias/clip, f16 out",
                        "m_per_gpu": M, "n": N, "k": K, "sharding": "rows of x (M) across ranks; packed weights replicated by broadcast"},
-            "roofline": roofline, "hbm": hbm,
+            "roofline": roofline, "hbm": hbm, "prewarm_launches": PREWARM,
         }
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(M, N, K, seed)

@@ -454,31 +454,40 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
     return TVL_OK;
 }
 
-// Tile shape and split-K factor.  256x256 tiles when they fill the chip; otherwise smaller tiles and, when
-// even those leave most of the 256 CUs idle, the k range is split over blockIdx.y so that about 2-4
-// workgroups per CU stream the packed weights concurrently.  The split factor is bounded so that the
-// float32 partial slabs (written once, read once) stay below the bytes of the packed weights themselves.
+// Tile shape and split-K factor, chosen by a small cost model (microseconds, calibrated on MI355X with forced
+// configurations).  With q = workgroups per CU, a CU spends  fixed * ceil(q / occupancy)  on prologues/epilogues
+// and  steps_per_workgroup * (q == 1 ? step_alone : q * step_shared)  in the k loops (step_shared = time per
+// workgroup-step when the CU is shared; small tiles gain little from sharing, they are bound by the decode work).
+// Split-K adds one more launch plus writing and re-reading the float32 slabs (~8 TB/s: they mostly stay in the
+// Infinity Cache): it fills the chip when
+// the output has few tiles, and the slab term stops it where the partial sums would cost more than idle CUs.
 struct GemmPlan { int bm, bn, splits; };
+struct TileCost { int bm, bn, occupancy; double fixed_us, step_alone_us, step_shared_us; };
+static const TileCost TILE_COSTS[] = {
+    {256, 256, 1, 14.0, 1.57, 1.57},   // 8 waves, 96 KiB LDS
+    {128, 128, 2, 5.0, 0.70, 0.53},    // 4 waves, 48 KiB LDS
+    {64, 128, 2, 4.5, 0.45, 0.39},
+    {32, 128, 3, 4.0, 0.21, 0.21},
+};
 static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_bytes) {
-    GemmPlan p;
-    if (ceil_div(m, 256) * ceil_div(n, 256) >= 192) { p.bm = 256; p.bn = 256; p.splits = 1; return p; }
-    p.bm = m > 64 ? 128 : (m > 32 ? 64 : 32);
-    p.bn = 128;
-    const int64_t tiles = ceil_div(m, p.bm) * ceil_div(n, p.bn);
     const int64_t steps = k / BK;
-    int64_t s = 1;
-    if (tiles < 384) {
-        s = 768 / tiles;                                           // aim at ~3 workgroups per CU
-        const int64_t by_steps = steps / 2 > 0 ? steps / 2 : 1;    // at least two k steps per split
-        const int64_t by_bytes = k / (16 * m) > 0 ? k / (16 * m) : 1;  // slab bytes <= packed weight bytes
-        const int64_t by_ws = (int64_t)(workspace_bytes / ((size_t)m * n * sizeof(float)));
-        s = s < by_steps ? s : by_steps;
-        s = s < by_bytes ? s : by_bytes;
-        s = s < by_ws ? s : by_ws;
-        s = s < 1 ? 1 : (s > 64 ? 64 : s);
+    const int64_t max_by_ws = (int64_t)(workspace_bytes / ((size_t)m * n * sizeof(float)));
+    GemmPlan best{128, 128, 1};
+    double best_t = 1e30;
+    for (const TileCost& tc : TILE_COSTS) {
+        if (tc.bm > 32 && m <= tc.bm / 2) continue;   // more than half of the tile's rows would be padding
+        const int64_t tiles = ceil_div(m, tc.bm) * ceil_div(n, tc.bn);
+        for (int64_t s = 1; s <= 64; ++s) {
+            if (s > 1 && (s > max_by_ws || steps / s < 2 || tc.bm == 256)) break;
+            const int64_t per = ceil_div(steps, s);
+            const int64_t q = ceil_div(tiles * s, 256);
+            double t = (double)ceil_div(q, tc.occupancy) * tc.fixed_us +
+                       (double)per * (q == 1 ? tc.step_alone_us : (double)q * tc.step_shared_us);
+            if (s > 1) t += 2.5 + 2.0 * (double)s * (double)m * (double)n * 4.0 / 8.0e6;
+            if (t < best_t) { best_t = t; best = GemmPlan{tc.bm, tc.bn, (int)s}; }
+        }
     }
-    p.splits = (int)s;
-    return p;
+    return best;
 }
 
 size_t gemm_mfma_workspace_bytes(int64_t m, int64_t n, int64_t k) {
