@@ -272,6 +272,16 @@ def main():
                         "frac_of_hbm_peak": round(d_bytes / (d_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del pwd
 
+        # ---- the same workload with float32 activations (the reference layer's dtype): three exact bf16 planes on
+        # the matrix cores, float32 output
+        xf = torch.randn(M, K, device=dev)
+        yf = torch.empty((M, N), dtype=torch.float32, device=dev)
+        f_avg, _ = time_launches(lambda i: ops.ternary_matmul(xf, pw, scale, bias, 100.0, out=yf), 10, 3, rounds=3)
+        extra["f32_activations"] = {"shape": [M, N, K], "avg_call_ms": round(f_avg, 4),
+                                    "effective_TFLOPs": round(2.0 * M * N * K / (f_avg * 1e-3) / 1e12, 1),
+                                    "kernels": "tvl::split_f32_kernel + tvl::gemm_mfma_kernel<bf16> over 3K"}
+        del xf, yf
+
         if args.sweep:
             sweep = []
             shapes = [(mm, 4096, 4096) for mm in (1, 16, 64, 256, 1024, 4096)]

@@ -96,13 +96,18 @@ int tvl_quantize(const void* w, int w_dtype, int64_t numel, int mode, float thre
  * clip, the optional activation, then one rounding to y's type.
  * Replaces `ops.ternary_matmul(x, pw, scale, bias, clip)` at impl/tf/moondream/ternary.py:281 and
  * ScaledTernaryLinear.forward at binary/modules.py:101-109.
- * `workspace` (device, may be NULL) lets the library pick kernels that need scratch memory
- * (split-K partial sums); see tvl_ternary_matmul_workspace_bytes. */
+ * `workspace` (device, may be NULL, 256-byte aligned) lets the library pick kernels that need scratch
+ * memory: split-K partial sums, and for float32 activations the three bf16 planes x = hi + mid + lo
+ * (exact) that put a float32 product on the matrix cores.  Without it the same results come from
+ * slower kernels.  tvl_ternary_matmul_workspace_bytes_for(x_dtype, m, n, k) gives the size that enables
+ * everything; tvl_ternary_matmul_workspace_bytes(m, n, k) is the f16 / bf16 figure.  Contents need no
+ * initialisation and are not preserved; calls that share a workspace must be ordered on one stream. */
 int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x,
                        const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                        const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y,
                        void* workspace, size_t workspace_bytes, void* stream);
 size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k);
+size_t tvl_ternary_matmul_workspace_bytes_for(int x_dtype, int64_t m, int64_t n, int64_t k);
 
 /* Multiplication-free select-and-sum with DENSE float weights: res[m, i] = sum_{tm[i,k]>0} x[m,k]
  * - sum_{tm[i,k]<0} x[m,k].  Replaces ternary_mm at matrix_mul_tests.py:29-37 (f32 only). */

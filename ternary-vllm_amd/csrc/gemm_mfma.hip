@@ -109,7 +109,7 @@ template <typename TX, typename TY, int BM, int BN, int WAVES_M, int WAVES_N, bo
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
 gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
                  const float* __restrict__ scale, const float* __restrict__ bias, float clip, TY* __restrict__ y,
-                 int64_t ld_y, int tiles_n, int nblk, int steps_per_split) {
+                 int64_t ld_y, int tiles_n, int nblk, int steps_per_split, int w_steps) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;            // 32x32 MFMA tiles per wave
@@ -165,7 +165,7 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
     for (int t = 0; t < TN; ++t) {
         int gn = n0 + wc * WN + t * 32 + r;
         gn = gn < n ? gn : n - 1;
-        b_src[t] = pw + (int64_t)gn * ld_pw + 8 * h + (int64_t)kb0 * (BK / 4);
+        b_src[t] = pw + (int64_t)gn * ld_pw + 8 * h;
     }
 
     // ---- fragment read offsets -----------------------------------------------------------------
@@ -196,10 +196,15 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
     // consumer behind it.  The loop is unrolled by NBUF so that buffers and registers have static roles
     // (no rotation copies of registers whose loads are still in flight).
     uint64_t bq0[TN], bq1[TN], bq2[TN];  // packed weights (32 per lane and tile) of steps 3j, 3j+1, 3j+2
+    // The packed rows hold w_steps k steps; a k range longer than that re-reads them from the start (float32
+    // activations arrive as three bf16 planes side by side along k: the same weights multiply each plane).
     auto load_b = [&](int kb, uint64_t (&dst)[TN]) {
+        int kw = kb0 + kb;
+        kw = kw >= w_steps ? kw - w_steps : kw;
+        kw = kw >= w_steps ? kw - w_steps : kw;
 #pragma unroll
         for (int t = 0; t < TN; ++t)
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[t]) : "v"(b_src[t] + (int64_t)kb * (BK / 4)) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[t]) : "v"(b_src[t] + (int64_t)kw * (BK / 4)) : "memory");
     };
     auto wait_loads = [&](uint64_t (&q)[TN]) {
         if constexpr (TN == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]) : : "memory");
@@ -418,7 +423,7 @@ int launch_splitk_reduce(const float* slab, int splits, int64_t m, int64_t n, co
 template <typename TX, typename TY, int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
                       const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, int splits, float* slab,
-                      hipStream_t st) {
+                      int w_steps, hipStream_t st) {
     const int tiles_m = (int)ceil_div(m, BM), tiles_n = (int)ceil_div(n, BN);
     const int nblk = tiles_m * tiles_n;
     const size_t lds_bytes = (size_t)NBUF * BM * ROW_BYTES;
@@ -431,7 +436,7 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
         if (lds_bytes > 48 * 1024)
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(kern, dim3(nblk, splits), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip,
-                           slab, n, tiles_n, nblk, steps_per_split);
+                           slab, n, tiles_n, nblk, steps_per_split, w_steps);
         TVL_LAUNCH_CHECK();
         return launch_reduce<TY>(slab, splits, m, n, scale, bias, clip, act, y, ld_y, st);
     }
@@ -442,7 +447,7 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
         if (lds_bytes > 48 * 1024)                                                                                 \
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, y, \
-                           ld_y, tiles_n, nblk, 0);                                                                \
+                           ld_y, tiles_n, nblk, 0, w_steps);                                                       \
     } while (0)
     if (bias) {
         if (act == TVL_ACT_GELU_TANH) TVL_GM(true, TVL_ACT_GELU_TANH); else TVL_GM(true, TVL_ACT_NONE);
@@ -490,56 +495,111 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_byte
     return best;
 }
 
-size_t gemm_mfma_workspace_bytes(int64_t m, int64_t n, int64_t k) {
-    const GemmPlan p = plan_gemm(m, n, k, (size_t)1 << 40);
-    return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
-}
 
 template <typename TX, typename TY>
 static int launch_mfma_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
                           const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, void* workspace,
-                          size_t workspace_bytes, hipStream_t st) {
+                          size_t workspace_bytes, int w_steps, hipStream_t st) {
     const bool ws_ok = workspace != nullptr && aligned(workspace, 16);
     const GemmPlan p = plan_gemm(m, n, k, ws_ok ? workspace_bytes : 0);
     float* slab = (float*)workspace;
     if (p.bm == 256)
-        return launch_cfg<TX, TY, 256, 256, 1, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, 1, slab, st);
+        return launch_cfg<TX, TY, 256, 256, 1, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, 1, slab, w_steps, st);
     if (p.bm == 128)
-        return launch_cfg<TX, TY, 128, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, st);
+        return launch_cfg<TX, TY, 128, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, w_steps, st);
     if (p.bm == 64)
-        return launch_cfg<TX, TY, 64, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, st);
-    return launch_cfg<TX, TY, 32, 128, 1, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, st);
+        return launch_cfg<TX, TY, 64, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, w_steps, st);
+    return launch_cfg<TX, TY, 32, 128, 1, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, w_steps, st);
 }
 
 template <typename TX>
 static int launch_mfma_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
                          const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y,
-                         void* ws, size_t ws_bytes, hipStream_t st) {
+                         void* ws, size_t ws_bytes, int w_steps, hipStream_t st) {
     switch (y_dtype) {
-        case TVL_F32: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (float*)y, ld_y, ws, ws_bytes, st);
-        case TVL_F16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (f16*)y, ld_y, ws, ws_bytes, st);
-        case TVL_BF16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (bf16_t*)y, ld_y, ws, ws_bytes, st);
+        case TVL_F32: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (float*)y, ld_y, ws, ws_bytes, w_steps, st);
+        case TVL_F16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (f16*)y, ld_y, ws, ws_bytes, w_steps, st);
+        case TVL_BF16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (bf16_t*)y, ld_y, ws, ws_bytes, w_steps, st);
         default: set_error("ternary_matmul: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
     }
 }
 
+// ---- float32 activations -------------------------------------------------------------------------------------
+// x = hi + mid + lo with three bf16 numbers, exactly (8 + 8 + 8 significand bits): the matrix cores then compute
+// sum_k w_k hi_k + sum_k w_k mid_k + sum_k w_k lo_k with exact products and float32 accumulation - a float32 dot
+// product in a different summation order.  The three planes are written side by side along k ([m][3k] bf16) into the
+// workspace, so the GEMM is the bf16 kernel over a k range of 3k whose weight rows wrap around every k.
+__global__ void __launch_bounds__(256) split_f32_kernel(const float* __restrict__ x, int64_t m, int64_t k, int64_t ld_x,
+                                                        uint16_t* __restrict__ xs) {
+    const int64_t per_row = k / 8, total = m * per_row;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+        const int64_t row = u / per_row, c8 = u - row * per_row;
+        const float4* src = reinterpret_cast<const float4*>(x + row * ld_x + 8 * c8);
+        const float4 a = src[0], b = src[1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint16_t hi[8], mid[8], lo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t bits = __float_as_uint(v[i]);
+            const uint32_t hb = bits & 0xFFFF0000u;
+            const bool finite = (bits & 0x7F800000u) != 0x7F800000u;   // inf / nan: all of it in the first plane
+            const float r1 = finite ? v[i] - __uint_as_float(hb) : 0.0f;            // exact
+            const uint32_t mb = __float_as_uint(r1) & 0xFFFF0000u;
+            const float r2 = r1 - __uint_as_float(mb);                                // exact, <= 8 significant bits
+            hi[i] = (uint16_t)((finite ? hb : bits | ((bits & 0xFFFFu) ? 0x10000u : 0u)) >> 16);   // keep a nan a nan
+            mid[i] = (uint16_t)(mb >> 16);
+            lo[i] = (uint16_t)(__float_as_uint(r2) >> 16);
+        }
+        uint16_t* dst = xs + row * (3 * k) + 8 * c8;
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(hi);
+        *reinterpret_cast<uint4*>(dst + k) = *reinterpret_cast<const uint4*>(mid);
+        *reinterpret_cast<uint4*>(dst + 2 * k) = *reinterpret_cast<const uint4*>(lo);
+    }
+}
+
+static inline size_t split_bytes(int64_t m, int64_t k) { return ((size_t)m * 3 * k * 2 + 255) & ~(size_t)255; }
+
+size_t gemm_mfma_workspace_bytes(int x_dtype, int64_t m, int64_t n, int64_t k) {
+    if (x_dtype == TVL_F32) {
+        const GemmPlan p = plan_gemm(m, n, 3 * k, (size_t)1 << 40);
+        return split_bytes(m, k) + (p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0);
+    }
+    const GemmPlan p = plan_gemm(m, n, k, (size_t)1 << 40);
+    return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
+}
+
 bool gemm_mfma_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
-                         int64_t ld_pw) {
-    if (x_dtype != TVL_F16 && x_dtype != TVL_BF16) return false;
+                         int64_t ld_pw, const void* workspace, size_t workspace_bytes) {
     if (k % BK != 0 || k <= 0) return false;
-    if (!aligned(x, 16) || (ld_x * 2) % 16 != 0) return false;
     if (!aligned(pw, 8) || ld_pw % 8 != 0) return false;
-    if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return false;
-    if (ceil_div(m, 128) * ceil_div(n, 128) > INT32_MAX) return false;
+    if (m > INT32_MAX || n > INT32_MAX || 3 * k > INT32_MAX) return false;
+    if (ceil_div(m, 32) * ceil_div(n, 128) > INT32_MAX) return false;
+    if (x_dtype == TVL_F32) {   // needs room for the three bf16 planes
+        if (!aligned(x, 16) || (ld_x * 4) % 16 != 0) return false;
+        return workspace != nullptr && aligned(workspace, 256) && workspace_bytes >= split_bytes(m, k);
+    }
+    if (x_dtype != TVL_F16 && x_dtype != TVL_BF16) return false;
+    if (!aligned(x, 16) || (ld_x * 2) % 16 != 0) return false;
     return true;
 }
 
 int launch_gemm_mfma(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
                      int64_t ld_pw, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype,
                      int64_t ld_y, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const int w_steps = (int)(k / BK);
+    if (x_dtype == TVL_F32) {
+        uint16_t* xs = (uint16_t*)workspace;
+        int64_t g = ceil_div(m * (k / 8), 256);
+        g = g > 256 * 16 ? 256 * 16 : g;
+        hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)x, m, k, ld_x, xs);
+        TVL_LAUNCH_CHECK();
+        const size_t used = split_bytes(m, k);
+        return launch_mfma_x((const bf16_t*)xs, m, 3 * k, 3 * k, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y,
+                             (char*)workspace + used, workspace_bytes - used, w_steps, st);
+    }
     if (x_dtype == TVL_F16)
-        return launch_mfma_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
-    return launch_mfma_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
+        return launch_mfma_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, w_steps, st);
+    return launch_mfma_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, w_steps, st);
 }
 
 }  // namespace tvl

@@ -98,10 +98,16 @@ int tvl_quantize(const void* w, int w_dtype, int64_t numel, int mode, float thre
     return launch_quantize_dense(w, w_dtype, numel, mode, threshold, out, out_dtype, (hipStream_t)stream);
 }
 
+size_t tvl_ternary_matmul_workspace_bytes_for(int x_dtype, int64_t m, int64_t n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0 || k % 64 != 0) return 0;
+    if (x_dtype == TVL_F32) return gemm_mfma_workspace_bytes(TVL_F32, m, n, k);
+    return tvl_ternary_matmul_workspace_bytes(m, n, k);
+}
+
 size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0 || k % 64 != 0) return 0;
     // split-K partial sums for shapes that underfill the chip (the larger of the two kernels' wishes)
-    const size_t a = gemm_mfma_workspace_bytes(m, n, k);
+    const size_t a = gemm_mfma_workspace_bytes(TVL_F16, m, n, k);
     const size_t b = (m <= 32 && k % 256 == 0) ? gemm_skinny_workspace_bytes(m, n, k) : 0;
     const size_t c = (m <= 16 && k % 256 == 0) ? gemm_stream_workspace_bytes(m, n, k) : 0;
     const size_t ab = a > b ? a : b;
@@ -134,7 +140,7 @@ int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t
         return launch_gemm_stream(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     if (gemm_skinny_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
         return launch_gemm_skinny(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
-    if (gemm_mfma_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
+    if (gemm_mfma_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
         return launch_gemm_mfma(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     return launch_gemm_generic(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
 }

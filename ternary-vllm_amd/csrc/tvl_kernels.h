@@ -27,11 +27,11 @@ int launch_ternary_mm(const float* x, int64_t m, int64_t k, int64_t ld_x, const 
 
 // gemm_mfma.hip
 bool gemm_mfma_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
-                         int64_t ld_pw);
+                         int64_t ld_pw, const void* workspace, size_t workspace_bytes);
 int launch_gemm_mfma(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
                      int64_t ld_pw, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype,
                      int64_t ld_y, void* workspace, size_t workspace_bytes, hipStream_t st);
-size_t gemm_mfma_workspace_bytes(int64_t m, int64_t n, int64_t k);
+size_t gemm_mfma_workspace_bytes(int x_dtype, int64_t m, int64_t n, int64_t k);
 int launch_splitk_reduce(const float* slab, int splits, int64_t m, int64_t n, const float* scale, const float* bias, float clip,
                          int act, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     "tvl_ternary_matmul": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_f32,
                                     _c_int, _c_vp, _c_int, _c_i64, _c_vp, _c_sz, _c_vp]),
     "tvl_ternary_matmul_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "tvl_ternary_matmul_workspace_bytes_for": (_c_sz, [_c_int, _c_i64, _c_i64, _c_i64]),
     "tvl_ternary_mm_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_i64, _c_vp]),
     "tvl_fit_ternary_scale_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_i64, _c_vp,
                                            _c_sz, _c_vp]),
@@ -294,8 +295,8 @@ _ACTS = {None: ACT_NONE, "none": ACT_NONE, "gelu_tanh": ACT_GELU_TANH, "gelu": A
 _matmul_workspaces = {}
 
 
-def _matmul_workspace(device: torch.device, stream: int, m: int, n: int, k: int):
-    need = int(_lib.tvl_ternary_matmul_workspace_bytes(m, n, k))
+def _matmul_workspace(device: torch.device, stream: int, x_dtype: int, m: int, n: int, k: int):
+    need = int(_lib.tvl_ternary_matmul_workspace_bytes_for(x_dtype, m, n, k))
     if need == 0:
         return None, 0
     key = (device.index, stream)
@@ -339,7 +340,7 @@ def ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias:
             raise ValueError("ternary_matmul: `out` must be a contiguous [..., N] tensor matching x")
     with torch.cuda.device(x.device):
         stream = _stream(x)
-        ws_ptr, ws_bytes = _matmul_workspace(x.device, stream, m, n, k)
+        ws_ptr, ws_bytes = _matmul_workspace(x.device, stream, _dt(x2, "ternary_matmul(x)"), m, n, k)
         _check(_lib.tvl_ternary_matmul(x2.data_ptr(), _dt(x2, "ternary_matmul(x)"), m, k, _ld(x2), pw.data_ptr(), n, _ld(pw),
                                        scale.data_ptr(), bias.data_ptr() if bias is not None else None, float(clip_val),
                                        _ACTS[activation], y.data_ptr(), _dt(y, "ternary_matmul(out)"), _ld(y), ws_ptr, ws_bytes,

@@ -263,6 +263,26 @@ def test_matmul_few_rows_invalid_code_and_extremes(ops, dev, m, k):
     assert np.max(np.abs(got.cpu().numpy()[0] - want[0]) / np.maximum(1.0, np.abs(want[0]))) <= 1e-2 * 65504 * 2.0 ** -10
 
 
+@pytest.mark.parametrize("m,n,k", [(70, 96, 64), (300, 200, 1024), (17, 520, 4096)])
+def test_matmul_f32_activations_matrix_core_path(ops, dev, m, n, k):
+    """float32 activations run on the matrix cores as three exact bf16 planes (x = hi + mid + lo): full float32
+    inputs - 24 significant bits, wide exponent range, signed zeros, subnormals - against the float64 oracle."""
+    rng = np.random.default_rng(m + n + k)
+    x = (rng.normal(size=(m, k)) * np.exp2(rng.integers(-12, 12, size=(m, k)))).astype(np.float32)
+    x[0, :6] = [0.0, -0.0, 1e-40, -1e-40, 3.0e38, 1.17549435e-38]
+    _, pw, scale, b = _case(rng, m, n, k)
+    want = O.ternary_matmul(x.astype(np.float64), pw, scale, b, 1e38, acc_dtype=np.float64)
+    cpu_f32 = O.ternary_matmul(x, pw, scale, b, 1e38, acc_dtype=np.float32)
+    got = ops.ternary_matmul(torch.from_numpy(x).to(dev), torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev),
+                             torch.from_numpy(b).to(dev), 1e38).cpu().numpy()
+    mag = np.abs(x.astype(np.float64)) @ np.abs(O.unpack_format_c(pw, k).astype(np.float64)).T * scale + np.abs(b)  # sum of |terms|
+    rel_gpu = np.max(np.abs(got[1:] - want[1:]) / mag[1:])
+    rel_cpu = np.max(np.abs(cpu_f32[1:] - want[1:]) / mag[1:])
+    print(f"K={k}: max relative-to-sum-of-magnitudes error gpu {rel_gpu:.3e}  cpu float32 {rel_cpu:.3e}")
+    assert rel_gpu <= max(2.0 * rel_cpu, 2.0 ** -22)
+    assert np.all(np.isfinite(got[0])) or not np.all(np.isfinite(want[0]))
+
+
 def test_matmul_few_rows_without_workspace(ops, dev):
     """Through the raw C ABI with workspace = NULL: long k ranges need split-K scratch for the streaming kernel,
     so the call must fall back to a kernel that needs none - same bits on the exact grid."""
