@@ -223,3 +223,34 @@ def test_to_packed_inference_and_arena(tv, dev, tmp_path):
     with torch.no_grad():
         assert torch.allclose(blk.mlp.fc1(x), nn.functional.gelu(want_fc1, approximate="tanh"), atol=2e-6)  # fc1 carries the GELU
         assert torch.equal(blk.mixer.Wqkv(x), want_qkv)
+
+
+# ------------------------------------------------------------------------------ decode-loop harness
+
+def test_decode_harness_matches_dense_reference_and_graph_replay(dev):
+    """Packed matmuls inside a (small) Phi-style decoder: prefill + steps against the same stack with dense float32
+    torch layers; the graph-captured step reproduces the eager step bit for bit."""
+    from ternary_vllm_amd import decode_harness as dh
+    cfg = dh.DecoderConfig(hidden=256, heads=4, intermediate=1024, blocks=2, max_len=64)
+    torch.manual_seed(3)
+    prompt = torch.randn(2, 19, cfg.hidden, device=dev)
+    toks = [torch.randn(2, 1, cfg.hidden, device=dev) for _ in range(4)]
+
+    def run(reference, graph):
+        st = dh.TernaryDecoderStack(cfg, batch=2, device=dev, dtype=torch.float32, seed=11)
+        if reference:
+            st.linear = lambda layer, x: layer.reference(x)
+        outs = [st.prefill(prompt)]
+        if graph:
+            st.capture_decode(toks[0])
+        for t in toks:
+            outs.append((st.decode_graph(t) if graph else st.decode_step(t)).clone())
+        assert int(st.pos) == 19 + len(toks)
+        return outs
+
+    packed, dense, replay = run(False, False), run(True, False), run(False, True)
+    for a, b in zip(packed, dense):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
+    for a, b in zip(packed, replay):
+        assert torch.equal(a, b)
