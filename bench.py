@@ -237,8 +237,15 @@ def main():
         achieved_tf = flops / (avg_ms * 1e-3) / 1e12
         by = gemm_bytes(M, N, K, 2)
         big = (M + 255) // 256 * ((N + 255) // 256) >= 192
+        traffic = None
+        try:   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (only valid for the profiled shape)
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                if (M, N, K) == (4096, 4096, 4096):
+                    traffic = json.load(f)["gemm_4096x4096x4096_f16"]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved_tf / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved_tf / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
                     "kernel": "tvl::gemm_mfma_kernel<f16, f16, 256, 256, 1, 8, bias, none, no split>" if big else "tvl::gemm_mfma_kernel (small tiles / split-K)",
                     "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops,
                     "timing": f"one HIP event pair around the {args.steps} timed launches on the launch stream"}
