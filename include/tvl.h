@@ -109,6 +109,24 @@ int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t
 size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k);
 size_t tvl_ternary_matmul_workspace_bytes_for(int x_dtype, int64_t m, int64_t n, int64_t k);
 
+/* ---- binarized activations (larq `input_quantizer="ste_sign"`, impl/tf/moondream/ternary.py:36) ---- */
+
+/* xb[m, w] bit i = (x[m, 32w+i] >= 0)  (sign_ste, binary/modules.py:5-10: +1 where x >= 0, else -1); pad bits 0.
+ * xb: uint32 [m, ld_xb >= ceil(k/32)] (ld_xb == 0 means ceil(k/32)). */
+int tvl_sign_pack_bits(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, uint32_t* xb,
+                       int64_t ld_xb, void* stream);
+/* Packed format-C rows -> two bit planes: pos bit = (code >= 2) i.e. weight +1, neg bit = (code == 0) i.e.
+ * weight -1 (the (pos, neg) pair of the reference's pack_ternary, ternary.py:72-75).  Code 3 counts as +1.
+ * pos, neg: uint32 [n, ld_planes >= ceil(k/32)] (0 means ceil(k/32)). */
+int tvl_ternary_bitplanes(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, uint32_t* pos, uint32_t* neg,
+                          int64_t ld_planes, void* stream);
+/* y[m,n] = act(clip((sum_k s[m,k] t[n,k]) * scale[n] + bias[n])) with s = +-1 from xb and t from (pos, neg):
+ * 2 (popc(xb & pos) - popc(xb & neg)) - (popc(pos) - popc(neg)), integer-exact, then the matmul's epilogue.
+ * Equals tvl_ternary_matmul on the activations sign(x) bit for bit. */
+int tvl_popcount_matmul(const uint32_t* xb, int64_t m, int64_t ld_xb, const uint32_t* pos, const uint32_t* neg,
+                        int64_t n, int64_t ld_planes, int64_t k, const float* scale, const float* bias,
+                        float clip, int act, void* y, int y_dtype, int64_t ld_y, void* stream);
+
 /* Multiplication-free select-and-sum with DENSE float weights: res[m, i] = sum_{tm[i,k]>0} x[m,k]
  * - sum_{tm[i,k]<0} x[m,k].  Replaces ternary_mm at matrix_mul_tests.py:29-37 (f32 only). */
 int tvl_ternary_mm_f32(const float* x, int64_t m, int64_t k, int64_t ld_x, const float* tm,

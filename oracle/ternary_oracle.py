@@ -331,6 +331,55 @@ def fit_binary_scale(w: np.ndarray, quantization: str = "binary", neuron_scale: 
 # --------------------------------------------------------------------------
 
 
+# ---------------------------------------------------------------------------------------------
+# binarized activations: AND + popcount form (larq input_quantizer="ste_sign", impl/tf/moondream/ternary.py:36)
+# ---------------------------------------------------------------------------------------------
+
+def sign_bits(x: np.ndarray) -> np.ndarray:
+    """Sign bits of the activations, 32 per word, LSB first: bit = (x >= 0), i.e. sign_ste = +1
+    (binary/modules.py:5-10); pad bits 0.  x [M, K] -> uint32 [M, ceil(K/32)]."""
+    x = np.asarray(x)
+    m, k = x.shape
+    words = (k + 31) // 32
+    bits = np.zeros((m, words * 32), dtype=np.uint8)
+    bits[:, :k] = (x >= 0)
+    return np.packbits(bits.reshape(m, words, 32), axis=-1, bitorder="little").view(np.uint32).reshape(m, words)
+
+
+def ternary_bitplanes(pw: np.ndarray, k: int):
+    """(pos, neg) bit planes of packed format-C rows: pos = weight +1 (codes 2 and 3), neg = weight -1 (code 0) -
+    the two planes the reference's pack_ternary builds per element (impl/tf/moondream/ternary.py:72-75).
+    uint8 [N, >= ceil(K/4)] -> two uint32 [N, ceil(K/32)]."""
+    pw = np.asarray(pw, dtype=np.uint8)
+    n = pw.shape[0]
+    codes = np.stack([(pw >> (2 * i)) & 3 for i in range(4)], axis=-1).reshape(n, -1)[:, :k]
+    words = (k + 31) // 32
+    out = []
+    for plane in ((codes >= 2), (codes == 0)):
+        bits = np.zeros((n, words * 32), dtype=np.uint8)
+        bits[:, :k] = plane
+        out.append(np.packbits(bits.reshape(n, words, 32), axis=-1, bitorder="little").view(np.uint32).reshape(n, words))
+    return out[0], out[1]
+
+
+def popcount_matmul(xb: np.ndarray, pos: np.ndarray, neg: np.ndarray, scale, bias, clip, act: int = ACT_NONE) -> np.ndarray:
+    """sum_k s t = 2 (popc(xb & pos) - popc(xb & neg)) - (popc(pos) - popc(neg)), then the matmul's float32
+    epilogue (binary/modules.py:101-109 order)."""
+    def popc(a):
+        return np.unpackbits(np.ascontiguousarray(a).view(np.uint8), axis=-1).sum(axis=-1, dtype=np.int64)
+    p = popc(xb[:, None, :] & pos[None, :, :])
+    q = popc(xb[:, None, :] & neg[None, :, :])
+    dot = 2 * (p - q) - (popc(pos) - popc(neg))[None, :]
+    y = dot.astype(np.float32) * np.asarray(scale, dtype=np.float32)[None, :]
+    if bias is not None:
+        y = y + np.asarray(bias, dtype=np.float32)[None, :]
+    c = np.float32(abs(clip))
+    y = np.clip(y, -c, c)
+    if act == ACT_GELU_TANH:
+        y = gelu_tanh(y.astype(np.float64)).astype(np.float32)
+    return y
+
+
 def zero_out(x: np.ndarray) -> np.ndarray:
     """Keep flat element 0, zero the rest.  Export at ``custom_ops_mod.py:29``;
     behaviour pinned by ``zero_out_tests.py:9-10`` and

@@ -136,6 +136,8 @@ int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t
     TVL_REQUIRE(aligned(x, dtype_size(x_dtype)) && aligned(y, dtype_size(y_dtype)) && aligned(scale, 4) && aligned(bias, 4),
                 "ternary_matmul: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (gemv_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
+        return launch_gemv(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
     if (gemm_stream_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
         return launch_gemm_stream(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     if (gemm_skinny_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
@@ -143,6 +145,49 @@ int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t
     if (gemm_mfma_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
         return launch_gemm_mfma(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     return launch_gemm_generic(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
+}
+
+int tvl_sign_pack_bits(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, uint32_t* xb, int64_t ld_xb, void* stream) {
+    TVL_REQUIRE(m >= 0 && k >= 0, "sign_pack_bits: negative shape");
+    TVL_REQUIRE(float_dtype(x_dtype), "sign_pack_bits: dtype must be f32/f16/bf16, got %d", x_dtype);
+    if (ld_x == 0) ld_x = k;
+    if (ld_xb == 0) ld_xb = ceil_div(k, 32);
+    TVL_REQUIRE(ld_x >= k && ld_xb >= ceil_div(k, 32), "sign_pack_bits: row stride too small");
+    if (m == 0 || k == 0) return TVL_OK;
+    TVL_REQUIRE(x && xb, "sign_pack_bits: NULL pointer");
+    TVL_REQUIRE(aligned(x, dtype_size(x_dtype)) && aligned(xb, 4), "sign_pack_bits: misaligned pointer");
+    return launch_sign_bits(x, x_dtype, m, k, ld_x, xb, ld_xb, (hipStream_t)stream);
+}
+
+int tvl_ternary_bitplanes(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, uint32_t* pos, uint32_t* neg, int64_t ld_planes,
+                          void* stream) {
+    TVL_REQUIRE(n >= 0 && k >= 0, "ternary_bitplanes: negative shape");
+    if (ld_pw == 0) ld_pw = ceil_div(k, 4);
+    if (ld_planes == 0) ld_planes = ceil_div(k, 32);
+    TVL_REQUIRE(ld_pw >= ceil_div(k, 4) && ld_planes >= ceil_div(k, 32), "ternary_bitplanes: row stride too small");
+    if (n == 0 || k == 0) return TVL_OK;
+    TVL_REQUIRE(pw && pos && neg, "ternary_bitplanes: NULL pointer");
+    TVL_REQUIRE(aligned(pos, 4) && aligned(neg, 4), "ternary_bitplanes: misaligned pointer");
+    return launch_bitplanes(pw, n, k, ld_pw, pos, neg, ld_planes, (hipStream_t)stream);
+}
+
+int tvl_popcount_matmul(const uint32_t* xb, int64_t m, int64_t ld_xb, const uint32_t* pos, const uint32_t* neg, int64_t n, int64_t ld_planes,
+                        int64_t k, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, void* stream) {
+    TVL_REQUIRE(m >= 0 && n >= 0 && k >= 0, "popcount_matmul: negative shape");
+    TVL_REQUIRE(float_dtype(y_dtype), "popcount_matmul: output dtype must be f32/f16/bf16, got %d", y_dtype);
+    TVL_REQUIRE(act == TVL_ACT_NONE || act == TVL_ACT_GELU_TANH, "popcount_matmul: unknown activation %d", act);
+    TVL_REQUIRE(k <= (int64_t)1 << 30, "popcount_matmul: k too large for 32-bit counts");
+    if (ld_xb == 0) ld_xb = ceil_div(k, 32);
+    if (ld_planes == 0) ld_planes = ceil_div(k, 32);
+    if (ld_y == 0) ld_y = n;
+    TVL_REQUIRE(ld_xb >= ceil_div(k, 32) && ld_planes >= ceil_div(k, 32) && ld_y >= n, "popcount_matmul: row stride too small");
+    TVL_REQUIRE(!(clip != clip), "popcount_matmul: clip is NaN");
+    if (m == 0 || n == 0) return TVL_OK;
+    TVL_REQUIRE(y && scale, "popcount_matmul: NULL output or scale pointer");
+    TVL_REQUIRE(k == 0 || (xb && pos && neg), "popcount_matmul: NULL input pointer");
+    TVL_REQUIRE(aligned(xb, 4) && aligned(pos, 4) && aligned(neg, 4) && aligned(y, dtype_size(y_dtype)) && aligned(scale, 4) && aligned(bias, 4),
+                "popcount_matmul: misaligned pointer");
+    return launch_popcount_matmul(xb, m, ld_xb, pos, neg, n, ld_planes, k, scale, bias, clip, act, y, y_dtype, ld_y, (hipStream_t)stream);
 }
 
 int tvl_ternary_mm_f32(const float* x, int64_t m, int64_t k, int64_t ld_x, const float* tm, int64_t n, int64_t ld_tm, float* res,

@@ -50,6 +50,17 @@ int launch_gemm_stream(const void* x, int64_t m, int64_t k, int64_t ld_x, const 
                        size_t workspace_bytes, hipStream_t st);
 size_t gemm_stream_workspace_bytes(int64_t m, int64_t n, int64_t k);
 
+// gemv.hip
+bool gemv_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw);
+int launch_gemv(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
+                const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
+
+// popcount.hip
+int launch_sign_bits(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, uint32_t* xb, int64_t ld_xb, hipStream_t st);
+int launch_bitplanes(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, uint32_t* pos, uint32_t* neg, int64_t ld_planes, hipStream_t st);
+int launch_popcount_matmul(const uint32_t* xb, int64_t m, int64_t ld_xb, const uint32_t* pos, const uint32_t* neg, int64_t n, int64_t ld_planes,
+                           int64_t k, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
+
 // fit_scale.hip
 size_t fit_workspace_bytes();
 int launch_fit_ternary(const float* w, int64_t n, int64_t k, int64_t ld_w, int uniform, int iters, float* scale, float* latent,

@@ -48,6 +48,10 @@ SIGNATURES = {
                                     _c_int, _c_vp, _c_int, _c_i64, _c_vp, _c_sz, _c_vp]),
     "tvl_ternary_matmul_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tvl_ternary_matmul_workspace_bytes_for": (_c_sz, [_c_int, _c_i64, _c_i64, _c_i64]),
+    "tvl_sign_pack_bits": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_vp]),
+    "tvl_ternary_bitplanes": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp]),
+    "tvl_popcount_matmul": (_c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_f32, _c_int,
+                                     _c_vp, _c_int, _c_i64, _c_vp]),
     "tvl_ternary_mm_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_i64, _c_vp]),
     "tvl_fit_ternary_scale_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_i64, _c_vp,
                                            _c_sz, _c_vp]),
@@ -374,6 +378,78 @@ def ternary_mm(m: torch.Tensor, tm: torch.Tensor) -> torch.Tensor:
         _check(_lib.tvl_ternary_mm_f32(m.data_ptr(), m.shape[0], m.shape[1], _ld(m), tm.data_ptr(), tm.shape[0], _ld(tm),
                                        res.data_ptr(), _ld(res), _stream(m)))
     return res
+
+
+# --------------------------------------------------------------------------------------------
+# binarized activations (AND + popcount)
+# --------------------------------------------------------------------------------------------
+
+def sign_pack_bits(x: torch.Tensor) -> torch.Tensor:
+    """Sign bits of x, 32 per int32 word, LSB first: bit = (x >= 0) (``sign_ste``, ``binary/modules.py:5-10``)."""
+    x2 = _rows(_gpu(x, "sign_pack_bits(x)").reshape(-1, x.shape[-1]), "sign_pack_bits(x)")
+    m, k = x2.shape
+    xb = torch.empty((m, (k + 31) // 32), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(_lib.tvl_sign_pack_bits(x2.data_ptr(), _dt(x2, "sign_pack_bits(x)"), m, k, _ld(x2), xb.data_ptr(), _ld(xb), _stream(x)))
+    return xb.reshape(*x.shape[:-1], xb.shape[1])
+
+
+def ternary_bitplanes(pw: torch.Tensor, orig_dim: int):
+    """(pos, neg) bit planes (int32 ``[N, ceil(K/32)]``) of packed rows: weight +1 / weight -1."""
+    pw = _rows(_gpu(pw, "ternary_bitplanes(pw)"), "ternary_bitplanes(pw)")
+    n, k = pw.shape[0], int(orig_dim)
+    if pw.dtype != torch.uint8 or pw.shape[1] < (k + 3) // 4:
+        raise ValueError(f"ternary_bitplanes: pw must be uint8 [N, >= {(k + 3) // 4}], got {pw.dtype} {tuple(pw.shape)}")
+    pos = torch.empty((n, (k + 31) // 32), dtype=torch.int32, device=pw.device)
+    neg = torch.empty_like(pos)
+    with torch.cuda.device(pw.device):
+        _check(_lib.tvl_ternary_bitplanes(pw.data_ptr(), n, k, _ld(pw), pos.data_ptr(), neg.data_ptr(), _ld(pos), _stream(pw)))
+    return pos, neg
+
+
+def popcount_matmul(xb: torch.Tensor, pos: torch.Tensor, neg: torch.Tensor, orig_dim: int, scale: torch.Tensor,
+                    bias: Optional[torch.Tensor], clip_val: float, activation: Optional[str] = None,
+                    out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """``act(clip((sign(x) @ t^T) * scale + bias))`` from bit planes: AND + popcount, integer-exact accumulation."""
+    lead = xb.shape[:-1]
+    xb2 = _rows(_gpu(xb, "popcount_matmul(xb)").reshape(-1, xb.shape[-1]), "popcount_matmul(xb)")
+    pos = _rows(_gpu(pos, "popcount_matmul(pos)"), "popcount_matmul(pos)")
+    neg = _rows(_gpu(neg, "popcount_matmul(neg)"), "popcount_matmul(neg)")
+    k, words = int(orig_dim), (int(orig_dim) + 31) // 32
+    if any(t.dtype != torch.int32 for t in (xb2, pos, neg)) or xb2.shape[1] < words or pos.shape != neg.shape or pos.shape[1] < words:
+        raise ValueError("popcount_matmul: xb / pos / neg must be int32 bit planes with >= ceil(K/32) words per row")
+    if activation not in _ACTS:
+        raise ValueError(f"Unknown activation: {activation}")
+    m, n = xb2.shape[0], pos.shape[0]
+    scale = _vec(scale, n, xb.device, "scale")
+    bias = _vec(bias, n, xb.device, "bias") if bias is not None else None
+    y = torch.empty((m, n), dtype=out_dtype, device=xb.device)
+    with torch.cuda.device(xb.device):
+        _check(_lib.tvl_popcount_matmul(xb2.data_ptr(), m, _ld(xb2), pos.data_ptr(), neg.data_ptr(), n, _ld(pos), k, scale.data_ptr(),
+                                        bias.data_ptr() if bias is not None else None, float(clip_val), _ACTS[activation],
+                                        y.data_ptr(), _dt(y, "popcount_matmul(out)"), _ld(y), _stream(xb)))
+    return y.reshape(*lead, n)
+
+
+def binarized_ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias: Optional[torch.Tensor], clip_val: float,
+                             activation: Optional[str] = None, method: str = "auto", planes=None) -> torch.Tensor:
+    """The matmul with sign-binarized activations (larq ``input_quantizer="ste_sign"``, ``ternary.py:36``).
+
+    ``method="popcount"``: bit planes + AND/popcount kernels; ``"mfma"``: sign(x) as +-1 f16 through the fused matrix-core
+    matmul - the same integers, so the two agree bit for bit; ``"auto"`` takes popcount for up to 8 rows (it reads the
+    same 2 bits per weight and skips the decode) and the matrix cores otherwise (4x the popcount rate per CU).
+    ``planes`` = a cached ``ternary_bitplanes(pw, K)`` result."""
+    k = x.shape[-1]
+    rows = x.numel() // max(1, k)
+    if method == "auto":
+        method = "popcount" if rows <= 8 else "mfma"
+    if method == "popcount":
+        pos, neg = planes if planes is not None else ternary_bitplanes(pw, k)
+        return popcount_matmul(sign_pack_bits(x), pos, neg, k, scale, bias, clip_val, activation)
+    if method != "mfma":
+        raise ValueError(f"Unknown method: {method}")
+    s = torch.where(x >= 0, 1.0, -1.0).to(torch.float16)
+    return ternary_matmul(s, pw, scale, bias, clip_val, activation=activation, out_dtype=torch.float32)
 
 
 # --------------------------------------------------------------------------------------------

@@ -410,6 +410,49 @@ def test_matmul_full_size_4096(ops, dev):
     assert torch.equal(y2, 2 * y1)
 
 
+# ------------------------------------------------------------------------------ binarized activations (popcount)
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (1, 130, 31), (2, 64, 4096), (3, 200, 1000), (8, 96, 2048), (9, 70, 33), (64, 64, 64),
+                                   (100, 300, 1029), (257, 129, 4096)])
+def test_popcount_matmul_matches_oracle_and_matrix_core_path(ops, dev, m, n, k):
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    x = rng.normal(size=(m, k)).astype(np.float32)
+    x[0, 0] = -0.0
+    t = rng.integers(-1, 2, size=(n, k)).astype(np.int8)
+    pw = O.pack_format_c(t)
+    scale = rng.uniform(0.5, 1.5, size=(n,)).astype(np.float32)
+    bias = rng.normal(size=(n,)).astype(np.float32)
+    xt, pwt = torch.from_numpy(x).to(dev), torch.from_numpy(pw).to(dev)
+    st, bt = torch.from_numpy(scale).to(dev), torch.from_numpy(bias).to(dev)
+    xb = ops.sign_pack_bits(xt)
+    pos, neg = ops.ternary_bitplanes(pwt, k)
+    assert np.array_equal(xb.cpu().numpy().view(np.uint32), O.sign_bits(x))
+    wp, wn = O.ternary_bitplanes(pw, k)
+    assert np.array_equal(pos.cpu().numpy().view(np.uint32), wp) and np.array_equal(neg.cpu().numpy().view(np.uint32), wn)
+    want = O.popcount_matmul(O.sign_bits(x), wp, wn, scale, bias, 100.0)
+    got = ops.popcount_matmul(xb, pos, neg, k, st, bt, 100.0)
+    assert np.array_equal(got.cpu().numpy(), want)
+    for method in ("popcount", "mfma", "auto"):
+        y = ops.binarized_ternary_matmul(xt, pwt, st, bt, 100.0, method=method)
+        assert np.array_equal(y.cpu().numpy(), want), method
+    for xdt in (torch.float16, torch.bfloat16):   # the sign survives the cast
+        assert torch.equal(ops.sign_pack_bits(xt.to(xdt)), xb)
+
+
+def test_popcount_invalid_code_and_gelu(ops, dev):
+    rng = np.random.default_rng(3)
+    m, n, k = 5, 40, 256
+    x = rng.normal(size=(m, k)).astype(np.float32)
+    pw = rng.integers(0, 256, size=(n, k // 4 + 2)).astype(np.uint8)     # code 3 present, wider rows than needed
+    scale = np.full((n,), 0.05, np.float32)
+    wp, wn = O.ternary_bitplanes(pw, k)
+    want = O.popcount_matmul(O.sign_bits(x), wp, wn, scale, None, 100.0, act=O.ACT_GELU_TANH)
+    pos, neg = ops.ternary_bitplanes(torch.from_numpy(pw).to(dev), k)
+    got = ops.popcount_matmul(ops.sign_pack_bits(torch.from_numpy(x).to(dev)), pos, neg, k, torch.from_numpy(scale).to(dev), None, 100.0,
+                              activation="gelu_tanh")
+    assert np.max(np.abs(got.cpu().numpy() - want)) <= 1e-5
+
+
 def test_ternary_mm(ops, dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "ternary_mm.npz"))
     for size in (32, 256):

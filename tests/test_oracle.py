@@ -165,3 +165,26 @@ def test_gelu_tanh_values():
     ref = np.array([-0.0036373920817729943, -0.15880800939172324, 0.0, 0.34571400982514394, 0.8411919906082768,
                     2.996362607918227])
     np.testing.assert_allclose(O.gelu_tanh(x), ref, rtol=1e-12)
+
+
+def test_popcount_form_equals_dense_sign_matmul():
+    """AND + popcount over bit planes == sign(x) @ t^T (integers), for ragged K and every code incl. the invalid 3."""
+    rng = np.random.default_rng(77)
+    for m, n, k in ((1, 1, 1), (3, 5, 31), (4, 7, 32), (5, 9, 33), (6, 10, 100), (2, 4, 1029)):
+        x = rng.normal(size=(m, k)).astype(np.float32)
+        x[0, 0] = 0.0
+        x[-1, -1] = -0.0                                    # -0.0 >= 0 is true: +1, as in the reference's (x >= 0)
+        t = rng.integers(-1, 2, size=(n, k)).astype(np.int8)
+        pw = O.pack_format_c(t)
+        scale = rng.uniform(0.5, 1.5, size=(n,)).astype(np.float32)
+        bias = rng.normal(size=(n,)).astype(np.float32)
+        xb = O.sign_bits(x)
+        pos, neg = O.ternary_bitplanes(pw, k)
+        assert xb.shape == (m, (k + 31) // 32) and pos.shape == (n, (k + 31) // 32)
+        got = O.popcount_matmul(xb, pos, neg, scale, bias, 100.0)
+        s = np.where(x >= 0, 1.0, -1.0).astype(np.float32)
+        want = O.ternary_matmul(s, pw, scale, bias, 100.0, k=k)
+        assert np.array_equal(got, want)
+    pw = np.array([[0b11100100]], dtype=np.uint8)            # codes 0,1,2,3 -> -1, 0, +1, (+1 in the planes)
+    pos, neg = O.ternary_bitplanes(pw, 4)
+    assert pos[0, 0] == 0b1100 and neg[0, 0] == 0b0001
