@@ -274,7 +274,7 @@ def main():
             sd, bd = torch.ones(dn, device=dev), torch.zeros(dn, device=dev)
             d_avg, d_best, how = time_graph(lambda i: ops.ternary_matmul(xd, pwd[i % nd], sd, bd, 100.0, out=yd), 2 * nd, nd)
             d_bytes = gemm_bytes(1, dn, dk, 2)
-            hbm[tag] = {"kernel": "tvl::gemm_stream_kernel + tvl::splitk_reduce_kernel (2 launches)", "shape": [1, dn, dk], "timing": how,
+            hbm[tag] = {"kernel": "tvl::gemv_kernel (one launch: table-lookup decode + v_dot2c, wave-level DPP reduction)", "shape": [1, dn, dk], "timing": how,
                         "algorithmic_bytes": d_bytes, "avg_call_ms": round(d_avg, 5), "GBps": round(d_bytes / (d_avg * 1e-3) / 1e9, 1),
                         "frac_of_hbm_peak": round(d_bytes / (d_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del pwd

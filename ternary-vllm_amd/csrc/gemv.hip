@@ -1,35 +1,44 @@
-// Packed-ternary x activation product for very few activation rows (decode: m <= 8), one launch, no split-K.
+// Packed-ternary x activation product for very few activation rows (decode: m <= 4), one launch, no split-K.
 //
 // One wave owns CH output channels and walks the whole k range: per iteration of 2048 k every lane loads the 8 packed
-// bytes (32 weights) of each of its channels - a wave-instruction reads 512 contiguous bytes of one row - and the
-// matching 32 activations of every row (the activations are a few KiB: they come from L1/L2 after the first wave).
-// The 2-bit codes are decoded in registers to f16 pairs (v_perm / v_and_or / v_pk_fma, 1.25 VALU per weight, shared
-// by the rows) and multiplied with v_dot2c_f32_f16 / _bf16 (float32 accumulation; float32 activations: v_fma_f32).
-// The lanes' partial sums are added over the wave with DPP row shifts in a fixed order, then the fused epilogue.
-// No LDS, no barrier, no workspace: many small waves keep enough weight bytes in flight (32 waves per CU), and a
-// 4096 x 4096 layer is ONE ~3 us launch where the split-K kernels need two launches (~8 us).
-// The price is VALU work proportional to the row count, so gemv_supported() hands larger m x n x k to the
-// matrix-core streaming kernel.  Requires k % 32 == 0, 16-byte aligned activation rows, 8-byte aligned packed rows.
+// bytes (32 weights) of each of its channels - a wave-instruction reads 512 contiguous bytes of one row - and ONCE
+// the matching 32 activations of every row, which then serve all CH channels from registers.
+// Decode is a table lookup: a packed byte indexes a 256-entry LDS table of its four weights, ready in the multiply
+// type (two f16 / bf16 pairs, or four floats) - one shift-by-SDWA and one ds_read per 4 weights instead of 5 VALU
+// instructions, which is what bounds a one-row product on the vector ALUs.  Two copies of the table (odd / even
+// lanes) halve the bank conflicts of the data-dependent addresses.  The products go through v_dot2c_f32_f16 / _bf16
+// (float32 accumulation; float32 activations: v_fma_f32), the lanes' partial sums are added over the wave with DPP
+// row shifts in a fixed order, then the fused epilogue.  No barrier in the loop, no workspace: a 4096 x 4096 layer
+// is ONE short launch where the split-K kernels need two.
+// The VALU work still grows with the row count, so gemv_supported() hands larger m x n x k to the matrix-core
+// streaming kernel.  Requires k % 32 == 0, 16-byte aligned activation rows, 8-byte aligned packed rows.
 #include "tvl_common.h"
 #include "tvl_kernels.h"
-
-#include <algorithm>
 
 namespace tvl {
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// 4 codes of byte BYTE of `d` -> two registers of f16 pairs (w0, w1), (w2, w3); see gemm_mfma.hip for the arithmetic
-template <int BYTE>
-__device__ __forceinline__ void gv_decode4(uint32_t d, uint32_t& r01, uint32_t& r23) {
-    const uint32_t rep = __builtin_amdgcn_perm(d, d, 0x0C000C00u | BYTE | (BYTE << 16));
-    const uint32_t v01 = (rep & 0x000C0003u) | 0x64006400u;
-    const uint32_t v23 = (rep & 0x00C00030u) | 0x64006400u;
-    const half2v m01 = {(_Float16)1.0f, (_Float16)0.25f}, a01 = {(_Float16)-1025.0f, (_Float16)-257.0f};
-    const half2v m23 = {(_Float16)0.0625f, (_Float16)0.015625f}, a23 = {(_Float16)-65.0f, (_Float16)-17.0f};
-    r01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(half2v, v01), m01, a01));
-    r23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(half2v, v23), m23, a23));
+// table entry of one packed byte: its four weights (code - 1; code 3 -> +2) in the multiply type
+template <typename TX> struct LutEntry { uint32_t w01, w23; };          // two pairs of f16 / bf16
+template <> struct LutEntry<float> { float w[4]; };
+
+template <typename TX>
+__device__ __forceinline__ LutEntry<TX> make_entry(uint32_t byte) {
+    LutEntry<TX> e;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)((int)((byte >> (2 * i)) & 3u) - 1);
+    if constexpr (sizeof(TX) == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e.w[i] = v[i];
+    } else {
+        const TX h[4] = {from_float<TX>(v[0]), from_float<TX>(v[1]), from_float<TX>(v[2]), from_float<TX>(v[3])};
+        e.w01 = (uint32_t)__builtin_bit_cast(uint16_t, h[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[1]) << 16);
+        e.w23 = (uint32_t)__builtin_bit_cast(uint16_t, h[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[3]) << 16);
+    }
+    return e;
 }
 
 template <int v>
@@ -65,12 +74,17 @@ __device__ __forceinline__ void load_x32(const TX* p, XVec<TX>& v) {
     }
 }
 
-template <typename TX, typename TY, int CH, int ROWS>
-__global__ void __launch_bounds__(256) gemv_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n,
-                                                   int64_t ld_pw, const float* __restrict__ scale, const float* __restrict__ bias, float clip,
-                                                   int act, TY* __restrict__ y, int64_t ld_y) {
+template <typename TX, typename TY, int CH, int ROWS, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw,
+                                                          int n, int64_t ld_pw, const float* __restrict__ scale, const float* __restrict__ bias,
+                                                          float clip, int act, TY* __restrict__ y, int64_t ld_y) {
+    __shared__ LutEntry<TX> lut[2][256];
     const int lane = threadIdx.x & 63;
-    const int ch0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * CH;   // wave-uniform
+    for (int i = threadIdx.x; i < 512; i += 64 * WAVES) lut[i >> 8][i & 255] = make_entry<TX>(i & 255);
+    __syncthreads();
+    const LutEntry<TX>* my_lut = lut[lane & 1];
+
+    const int ch0 = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * CH;   // wave-uniform
     if (ch0 >= n) return;
     const uint8_t* wrow[CH];
 #pragma unroll
@@ -88,44 +102,40 @@ __global__ void __launch_bounds__(256) gemv_kernel(const TX* __restrict__ x, int
         uint2 wq[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) wq[c] = *reinterpret_cast<const uint2*>(wrow[c] + (k0 - 32 * lane) / 4);
-        uint32_t wd[CH][16];   // 32 decoded weights per channel as f16 (or bf16) pairs
+        XVec<TX> xv[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) load_x32<TX>(x + (int64_t)(r < m ? r : 0) * ld_x + k0, xv[r]);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            gv_decode4<0>(wq[c].x, wd[c][0], wd[c][1]);   gv_decode4<1>(wq[c].x, wd[c][2], wd[c][3]);
-            gv_decode4<2>(wq[c].x, wd[c][4], wd[c][5]);   gv_decode4<3>(wq[c].x, wd[c][6], wd[c][7]);
-            gv_decode4<0>(wq[c].y, wd[c][8], wd[c][9]);   gv_decode4<1>(wq[c].y, wd[c][10], wd[c][11]);
-            gv_decode4<2>(wq[c].y, wd[c][12], wd[c][13]); gv_decode4<3>(wq[c].y, wd[c][14], wd[c][15]);
-            if constexpr (__is_same(TX, bf16_t)) {
+            LutEntry<TX> e[8];   // 32 weights of channel c
 #pragma unroll
-                for (int i = 0; i < 16; ++i) wd[c][i] |= (wd[c][i] >> 3) & 0x03800380u;   // f16 patterns of {-1,0,1,2} -> bf16
-            }
-        }
+            for (int b = 0; b < 8; ++b) e[b] = my_lut[((b < 4 ? wq[c].x : wq[c].y) >> (8 * (b & 3))) & 0xFFu];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            if (r < m) {
-                XVec<TX> xv;
-                load_x32<TX>(x + (int64_t)r * ld_x + k0, xv);
+            for (int r = 0; r < ROWS; ++r) {
+                // two accumulation chains per output keep dependent dot instructions apart
+                float a0 = acc[r][c], a1 = 0.0f;
+                if constexpr (__is_same(TX, f16)) {
 #pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    float a = acc[r][c];
-                    if constexpr (__is_same(TX, f16)) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            a = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, wd[c][i]), __builtin_bit_cast(half2v, xv.r[i]), a, false);
-                    } else if constexpr (__is_same(TX, bf16_t)) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wd[c][i]), __builtin_bit_cast(bf16x2, xv.r[i]), a, false);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const half2v w2 = __builtin_bit_cast(half2v, wd[c][i]);
-                            a = __builtin_fmaf((float)w2[0], xv.r[2 * i], a);
-                            a = __builtin_fmaf((float)w2[1], xv.r[2 * i + 1], a);
-                        }
+                    for (int b = 0; b < 8; ++b) {
+                        a0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, e[b].w01), __builtin_bit_cast(half2v, xv[r].r[2 * b]), a0, false);
+                        a1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, e[b].w23), __builtin_bit_cast(half2v, xv[r].r[2 * b + 1]), a1, false);
                     }
-                    acc[r][c] = a;
+                } else if constexpr (__is_same(TX, bf16_t)) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        a0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, e[b].w01), __builtin_bit_cast(bf16x2, xv[r].r[2 * b]), a0, false);
+                        a1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, e[b].w23), __builtin_bit_cast(bf16x2, xv[r].r[2 * b + 1]), a1, false);
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        a0 = __builtin_fmaf(e[b].w[0], xv[r].r[4 * b], a0);
+                        a1 = __builtin_fmaf(e[b].w[1], xv[r].r[4 * b + 1], a1);
+                        a0 = __builtin_fmaf(e[b].w[2], xv[r].r[4 * b + 2], a0);
+                        a1 = __builtin_fmaf(e[b].w[3], xv[r].r[4 * b + 3], a1);
+                    }
                 }
+                acc[r][c] = a0 + a1;
             }
         }
     }
@@ -134,52 +144,52 @@ __global__ void __launch_bounds__(256) gemv_kernel(const TX* __restrict__ x, int
     const bool has_bias = bias != nullptr;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        if (r < m) {
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const float s = gv_wave_sum(acc[r][c]);
-                const int ch = ch0 + c;
-                if (lane == 0 && ch < n)
-                    y[(int64_t)r * ld_y + ch] = from_float<TY>(epilogue_rt(s, scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl));
-            }
+        for (int c = 0; c < CH; ++c) {
+            const float s = gv_wave_sum(acc[r][c]);
+            const int ch = ch0 + c;
+            if (lane == 0 && r < m && ch < n)
+                y[(int64_t)r * ld_y + ch] = from_float<TY>(epilogue_rt(s, scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl));
         }
     }
 }
 
-// This kernel's time is ~ launch + max(bytes / stream rate, weights * (1.25 + a * m) VALU lane-operations / chip rate);
-// the split-K matrix-core kernels cost two launches plus the stream.  Few rows or a small layer: this kernel.
+// Chosen against the two-launch split-K kernels by measured cost (microseconds; W = n * k / 1e6): this kernel
+// ~ 2.5 + W * (0.045 + 0.0255 m) (x 1.4 in the 2-channels-per-wave geometry), the streaming kernel + reduce
+// ~ 6 + 0.0735 W.  One or two rows, or a small layer: this kernel.
 bool gemv_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw) {
     if (x_dtype != TVL_F16 && x_dtype != TVL_BF16 && x_dtype != TVL_F32) return false;
-    if (m < 1 || m > 8 || k <= 0 || k % 32 != 0) return false;
+    if (m < 1 || m > 4 || k <= 0 || k % 32 != 0) return false;
     const int64_t esz = x_dtype == TVL_F32 ? 4 : 2;
     if (!aligned(x, 16) || (ld_x * esz) % 16 != 0) return false;
     if (!aligned(pw, 8) || ld_pw % 8 != 0) return false;
     if (n > INT32_MAX / 2 || k > INT32_MAX) return false;
-    const double per_weight = (x_dtype == TVL_F32 ? 2.25 + 2.0 * m : (x_dtype == TVL_BF16 ? 2.25 : 1.25) + 0.5 * m);
-    const double weights = (double)n * (double)k;
-    const double t_gemv = 2.5 + std::max(weights / 4.0 / 3.8e6, weights * per_weight / 39.0e6);       // microseconds
-    const double t_other = x_dtype == TVL_F32 ? 25.0 + weights * 3.0 * 2.0 * 32.0 / 1.0e9               // split + bf16 GEMM over 3K (32-row tiles)
-                                               : 6.0 + weights / 4.0 / 3.4e6;                            // streaming kernel + reduce launch
+    const double w = (double)n * (double)k / 1.0e6;
+    const double per = x_dtype == TVL_F32 ? 0.045 + 0.05 * m : 0.045 + 0.0255 * m;
+    const double t_gemv = 2.5 + w * per * (n < 16384 ? 1.4 : 1.0);
+    const double t_other = x_dtype == TVL_F32 ? 25.0 + 0.2 * w     // plane split + bf16 GEMM over 3K on 32-row tiles
+                                               : 6.0 + 0.0735 * w;  // streaming kernel + reduce launch
     return t_gemv <= t_other;
+}
+
+template <typename TX, typename TY, int CH, int WAVES>
+static void launch_gemv_rows(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
+                             const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div(n, CH * WAVES)), block(64 * WAVES);
+    if (m == 1)
+        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 1, WAVES>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
+    else if (m == 2)
+        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 2, WAVES>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
+    else
+        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 4, WAVES>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
 }
 
 template <typename TX, typename TY>
 static int launch_gemv_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                           const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
-    const dim3 block(256);
-    if (m <= 2) {
-        constexpr int CH = 2;
-        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 2>), dim3((unsigned)ceil_div(n, 4 * CH)), block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw,
-                           scale, bias, clip, act, y, ld_y);
-    } else if (m <= 4) {
-        constexpr int CH = 2;
-        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 4>), dim3((unsigned)ceil_div(n, 4 * CH)), block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw,
-                           scale, bias, clip, act, y, ld_y);
-    } else {
-        constexpr int CH = 2;
-        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 8>), dim3((unsigned)ceil_div(n, 4 * CH)), block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw,
-                           scale, bias, clip, act, y, ld_y);
-    }
+    // few channels: 2 per wave so that the layer still makes >= 2 waves per SIMD; many: 8 per wave (activations reused)
+    if (n < 16384) launch_gemv_rows<TX, TY, 2, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
+    else launch_gemv_rows<TX, TY, 8, 1>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
     TVL_LAUNCH_CHECK();
     return TVL_OK;
 }

@@ -192,7 +192,8 @@ SHAPES = [(1, 1, 1), (1, 8, 4), (3, 5, 7), (17, 33, 30), (64, 64, 64), (65, 130,
           (1, 128, 64), (7, 100, 128), (32, 128, 256), (33, 64, 192), (64, 256, 512), (100, 300, 640),  # MFMA, small tiles
           (129, 129, 64), (200, 512, 1024), (745, 2048, 2048),
           (1, 128, 256), (1, 4096, 4096), (3, 200, 768), (16, 130, 512), (31, 6144, 2048), (32, 256, 1024), (8, 96, 3072),  # few rows:
-          (2, 1000, 16384), (5, 129, 8192), (9, 64, 1280), (12, 520, 4352), (16, 2048, 8192), (1, 30, 32768)]        # streaming kernels
+          (2, 1000, 16384), (5, 129, 8192), (9, 64, 1280), (12, 520, 4352), (16, 2048, 8192), (1, 30, 32768),         # streaming kernels
+          (1, 7, 32), (2, 9, 96), (3, 130, 2080), (4, 2050, 2048), (1, 16390, 4096), (4, 16384, 160)]                 # single-launch decode kernel
 
 
 @pytest.mark.parametrize("m,n,k", SHAPES)
@@ -245,7 +246,7 @@ def test_matmul_invalid_code_and_padding(ops, dev, k):
         assert np.array_equal(got.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("m,k", [(1, 256), (4, 1024), (13, 8192)])
+@pytest.mark.parametrize("m,k", [(1, 256), (4, 1024), (13, 8192), (2, 96)])
 def test_matmul_few_rows_invalid_code_and_extremes(ops, dev, m, k):
     """The few-row kernel feeds the raw 2-bit codes to the matrix cores as f16 subnormals: every code value
     (3 included, decoding as +2) at every bit position, and activations at the ends of the f16 range."""
