@@ -246,7 +246,7 @@ def main():
             pass
         roofline = {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved_tf / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "tvl::gemm_mfma_kernel<f16, f16, 256, 256, 1, 8, bias, none, no split>" if big else "tvl::gemm_mfma_kernel (small tiles / split-K)",
+                    "kernel": "tvl::gemm_mfma16_kernel<f16, f16, bias, none> (256x256 tile, v_mfma_f32_16x16x32_f16)" if big else "tvl::gemm_mfma_kernel (small tiles / split-K)",
                     "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops,
                     "timing": f"one HIP event pair around the {args.steps} timed launches on the launch stream"}
         hbm = {"gemm_algorithmic_bytes": by, "gemm_GBps": round(by / (avg_ms * 1e-3) / 1e9, 1),

@@ -367,6 +367,229 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
     }
 }
 
+// ---- the 256 x 256 tile on v_mfma_f32_16x16x32 -------------------------------------------------------------------
+// Same workgroup tile, wave tile (256 rows x 32 channels), LDS image, staging and pipeline as gemm_mfma_kernel with
+// <256, 256, 1, 8>; only the matrix instruction differs.  Cycles per flop are equal, but under matrix-core load the
+// chip holds a higher clock on this shape (measured by in-process A/B on random data), so it is the one used for
+// the big tile.  Operand layout: lane (c = lane & 15, g = lane >> 4) holds 8 consecutive k of weight row c
+// (operand A) and of activation row c (operand B); D register e is channel 4 g + e, activation row c.
+// k order inside a 64-step: lane group g owns k = 16 q .. 16 q + 15 with q = {0, 3, 1, 2}[g] (one dword of packed
+// weights per 16-channel tile); MFMA group s = 0, 1 takes the dword's halfword s and the activation chunk 2 q + s.
+// That assignment of q keeps the swizzled ds_read_b128 fragment reads conflict-free: the two lane groups that share
+// an LDS cycle read chunk indices whose bits 1 and 2 have equal parity.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <typename TX>
+__device__ __forceinline__ floatx4 mfma16(uint4 a, uint4 b, floatx4 c) {
+    if constexpr (__is_same(TX, f16)) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+}
+
+template <typename TX, typename TY, bool HAS_BIAS, int ACT>
+__global__ void __launch_bounds__(512, 2)
+gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
+                   const float* __restrict__ scale, const float* __restrict__ bias, float clip, TY* __restrict__ y,
+                   int64_t ld_y, int tiles_n, int nblk, int w_steps) {
+    constexpr int BM = 256, BN = 256, NT = 512;
+    constexpr int A_TILE_BYTES = BM * ROW_BYTES;
+    constexpr int ROUNDS = (BM * 8) / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NBUF * A_TILE_BYTES
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int q = (0x2130 >> (4 * g)) & 3;
+    const int tile = xcd_remap(blockIdx.x, nblk);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int nk = k / BK;
+
+    const TX* a_src[ROUNDS];
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+        const int p = i * NT + tid;
+        const int row = p >> 3, cs = p & 7;
+        const int chunk = cs ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < m ? gm : m - 1;
+        a_src[i] = x + (int64_t)gm * ld_x + chunk * 8;
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
+    auto stage_a = [&](int kb, int buf) {
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + buf * A_TILE_BYTES + (i * NT + wid * 64) * 16);
+            const TX* src = a_src[i] + (int64_t)kb * BK;
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+    };
+
+    const uint8_t* b_src[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int gn = n0 + wid * 32 + t * 16 + c;
+        gn = gn < n ? gn : n - 1;
+        b_src[t] = pw + (int64_t)gn * ld_pw + 4 * q;
+    }
+    auto load_b = [&](int kb, uint32_t (&dst)[2]) {
+        int kw = kb;
+        kw = kw >= w_steps ? kw - w_steps : kw;
+        kw = kw >= w_steps ? kw - w_steps : kw;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            asm volatile("global_load_dword %0, %1, off" : "=v"(dst[t]) : "v"(b_src[t] + (int64_t)kw * (BK / 4)) : "memory");
+    };
+    auto wait_loads = [&](uint32_t (&w)[2]) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]) : : "memory"); };
+
+    const int sw = (c >> 1) & 7;                 // (row >> 1) & 7 with row = 16 i + c
+    const int a_row_off = c * ROW_BYTES;
+    int a_col_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a_col_off[s] = ((2 * q + s) ^ sw) * 16;
+
+    floatx4 acc[16][2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[i][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    const DecodeConsts dc = make_decode_consts();
+
+    auto read_a = [&](int buf, int s, int half, uint4 (&af)[8]) {
+        const unsigned char* abase = lds + buf * A_TILE_BYTES + a_row_off + a_col_off[s] + half * 8 * 16 * ROW_BYTES;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const uint4*>(abase + i * 16 * ROW_BYTES);
+    };
+    auto decode_b = [&](uint32_t d, int s) { return s ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc); };
+    auto mma = [&](const uint4 (&af)[8], int half, const uint4 (&bf)[2]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[8 * half + i][t] = mfma16<TX>(bf[t], af[i], acc[8 * half + i][t]);
+    };
+    auto interleave_hint = [&]() {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // 1 decode / address VALU
+        }
+    };
+
+    uint32_t bq0[2], bq1[2], bq2[2];   // packed weights (16 per lane and tile) of steps 3j, 3j+1, 3j+2
+    uint4 afA[8], afB[8], bf0[2], bf1[2];   // bf0 / bf1: decoded weights of MFMA group s = 0 / 1
+    // one step = four phases (s, half of the 16 row tiles); each phase reads the NEXT phase's activation fragments
+    // first, then interleaves its 16 MFMAs with the decode of one weight fragment needed two phases later
+    auto step = [&](int kb, auto buf_c, uint32_t (&w0)[2], uint32_t (&w1)[2], uint32_t (&w2)[2]) {
+        constexpr int buf = decltype(buf_c)::value;
+        constexpr int buf1 = (buf + 1) % NBUF, buf2 = (buf + 2) % NBUF;
+        read_a(buf, 0, 1, afB);
+        __builtin_amdgcn_sched_barrier(0);
+        bf1[0] = decode_b(w0[0], 1); mma(afA, 0, bf0);
+        interleave_hint();
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(buf, 1, 0, afA);
+        __builtin_amdgcn_sched_barrier(0);
+        bf1[1] = decode_b(w0[1], 1); mma(afB, 1, bf0);
+        interleave_hint();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- middle of the step: tile kb+1 (and its weights w1) complete, tile kb-1 retired ----
+        wait_loads(w1);
+        __builtin_amdgcn_s_barrier();
+        const int kn = kb + 2 < nk ? kb + 2 : nk - 1;
+        read_a(buf, 1, 1, afB);
+        stage_a(kn, buf2); load_b(kn, w2);
+        __builtin_amdgcn_sched_barrier(0);
+        bf0[0] = decode_b(w1[0], 0); mma(afA, 0, bf1);
+        interleave_hint();
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(buf1, 0, 0, afA);
+        __builtin_amdgcn_sched_barrier(0);
+        bf0[1] = decode_b(w1[1], 0); mma(afB, 1, bf1);
+        interleave_hint();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    stage_a(0, 0);
+    load_b(0, bq0);
+    if (nk > 1) { stage_a(1, 1); load_b(1, bq1); }
+    else { bq1[0] = bq1[1] = 0; }
+    bq2[0] = bq2[1] = 0;
+    wait_loads(bq0);
+    wait_loads(bq1);
+    __builtin_amdgcn_s_barrier();
+    read_a(0, 0, 0, afA);
+    bf0[0] = decode_b(bq0[0], 0);
+    bf0[1] = decode_b(bq0[1], 0);
+    for (int kb = 0; kb < nk; kb += NBUF) {
+        step(kb, std::integral_constant<int, 0>{}, bq0, bq1, bq2);
+        if (kb + 1 < nk) step(kb + 1, std::integral_constant<int, 1>{}, bq1, bq2, bq0);
+        if (kb + 2 < nk) step(kb + 2, std::integral_constant<int, 2>{}, bq2, bq0, bq1);
+    }
+    wait_loads(bq0);
+    wait_loads(bq1);
+    wait_loads(bq2);
+
+    // ---- epilogue: lane (c, g) owns activation row 16 i + c and channels 16 t + 4 g + e -------------------------------
+    // 16-bit outputs: v_permlane16_swap hands even lane groups their neighbour's 4 channels of tile 0 and odd lane
+    // groups their neighbour's 4 channels of tile 1, so every lane stores 16 contiguous bytes.
+    const float cl = fabsf(clip);
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) | (uintptr_t)(ld_y * (int64_t)sizeof(TY))) & 15) == 0;
+    const int nb = n0 + wid * 32;
+    float sc[2][4], bi[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gn = nb + 16 * t + 4 * g + e;
+            sc[t][e] = gn < n ? scale[gn] : 0.0f;
+            bi[t][e] = (HAS_BIAS && gn < n) ? bias[gn] : 0.0f;
+        }
+    const int noff = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;   // first of the 8 channels a lane stores after the swap
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int gm = m0 + 16 * i + c;
+        float v[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[t][e] = epilogue<HAS_BIAS, ACT>(acc[i][t][e], sc[t][e], bi[t][e], cl);
+        TY* yrow = y + (int64_t)(gm < m ? gm : 0) * ld_y;
+        if (vec_ok && nb + 32 <= n) {
+            if constexpr (sizeof(TY) == 4) {
+                if (gm < m) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        *reinterpret_cast<float4*>(yrow + nb + 16 * t + 4 * g) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
+                }
+            } else {
+                uint2 pk[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    TY tmp[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tmp[e] = from_float<TY>(v[t][e]);
+                    pk[t] = *reinterpret_cast<const uint2*>(tmp);
+                }
+                // all 64 lanes take part in the swap (no divergence above this point)
+                auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+                auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+                const uint4 out = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                if (gm < m) *reinterpret_cast<uint4*>(yrow + nb + noff) = out;
+            }
+        } else if (gm < m) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gn = nb + 16 * t + 4 * g + e;
+                    if (gn < n) yrow[gn] = from_float<TY>(v[t][e]);
+                }
+        }
+    }
+}
+
 // Sum the split-K slabs in a fixed order (deterministic: slab 0, 1, 2, ...) and apply the fused epilogue.
 // One thread per output element; the slab loads of 8 consecutive splits are issued together (they are
 // independent; a one-load-at-a-time loop would pay the memory latency `splits` times).
@@ -443,6 +666,13 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
     const dim3 grid(nblk);
 #define TVL_GM(HB, ACT)                                                                                            \
     do {                                                                                                           \
+        if constexpr (BM == 256) {   /* the big tile runs on the 16x16x32 instruction */                            \
+            auto k16 = gemm_mfma16_kernel<TX, TY, HB, ACT>;                                                        \
+            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+            hipLaunchKernelGGL(k16, grid, block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, y, \
+                               ld_y, tiles_n, nblk, w_steps);                                                      \
+            break;                                                                                                 \
+        }                                                                                                          \
         auto kern = gemm_mfma_kernel<TX, TY, BM, BN, WAVES_M, WAVES_N, HB, ACT, false>;                             \
         if (lds_bytes > 48 * 1024)                                                                                 \
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \

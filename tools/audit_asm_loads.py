@@ -9,6 +9,18 @@ N youngest.  The listing is walked twice so that loads still in flight at a loop
 import re
 import sys
 
+
+
+def load_dest(line):
+    """Destination registers of a global_load_dword[x2|x3|x4] (empty set for anything else, LDS-DMA included)."""
+    m = re.search(r"global_load_dword(?:x[234])? (?:v\[(\d+):(\d+)\]|v(\d+)),", line)
+    if not m:
+        return set()
+    if m.group(3) is not None:
+        return {int(m.group(3))}
+    return set(range(int(m.group(1)), int(m.group(2)) + 1))
+
+
 s = open(sys.argv[1]).read()
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
 names = [n for n in re.findall(r"^(_Z\S+):", s, flags=re.M) if pat in n]
@@ -27,9 +39,7 @@ for name in names:
         elif "#ASMEND" in l:
             in_asm = False
         elif in_asm:
-            m = re.search(r"global_load_dwordx[24] v\[(\d+):(\d+)\]", l)
-            if m:
-                dests.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            dests.update(load_dest(l))
     if not dests:
         continue
     last_wait = None
@@ -61,8 +71,7 @@ for name in names:
             last_wait = i
             continue
         if re.match(r"\s*(global|buffer|flat|scratch)_(load|store|atomic)", l):
-            m = re.search(r"global_load_dwordx[24] v\[(\d+):(\d+)\]", l) if in_asm else None
-            fifo.append((i, set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()))
+            fifo.append((i, load_dest(l) if in_asm else set()))
             continue
         if in_asm:
             continue
