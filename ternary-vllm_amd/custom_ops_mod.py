@@ -299,8 +299,14 @@ _ACTS = {None: ACT_NONE, "none": ACT_NONE, "gelu_tanh": ACT_GELU_TANH, "gelu": A
 _matmul_workspaces = {}
 
 
+_workspace_need = {}
+
+
 def _matmul_workspace(device: torch.device, stream: int, x_dtype: int, m: int, n: int, k: int):
-    need = int(_lib.tvl_ternary_matmul_workspace_bytes_for(x_dtype, m, n, k))
+    shape_key = (x_dtype, m, n, k)
+    need = _workspace_need.get(shape_key)
+    if need is None:
+        need = _workspace_need[shape_key] = int(_lib.tvl_ternary_matmul_workspace_bytes_for(x_dtype, m, n, k))
     if need == 0:
         return None, 0
     key = (device.index, stream)
@@ -342,17 +348,60 @@ def ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias:
         y = _rows(_gpu(out, "ternary_matmul(out)").reshape(-1, n), "ternary_matmul(out)")
         if y.shape[0] != m or y.data_ptr() != out.data_ptr():
             raise ValueError("ternary_matmul: `out` must be a contiguous [..., N] tensor matching x")
-    with torch.cuda.device(x.device):
+    xdt = _dt(x2, "ternary_matmul(x)")
+
+    def launch():
         stream = _stream(x)
-        ws_ptr, ws_bytes = _matmul_workspace(x.device, stream, _dt(x2, "ternary_matmul(x)"), m, n, k)
-        _check(_lib.tvl_ternary_matmul(x2.data_ptr(), _dt(x2, "ternary_matmul(x)"), m, k, _ld(x2), pw.data_ptr(), n, _ld(pw),
+        ws_ptr, ws_bytes = _matmul_workspace(x.device, stream, xdt, m, n, k)
+        _check(_lib.tvl_ternary_matmul(x2.data_ptr(), xdt, m, k, _ld(x2), pw.data_ptr(), n, _ld(pw),
                                        scale.data_ptr(), bias.data_ptr() if bias is not None else None, float(clip_val),
                                        _ACTS[activation], y.data_ptr(), _dt(y, "ternary_matmul(out)"), _ld(y), ws_ptr, ws_bytes,
                                        stream))
-    return y.reshape(*lead, n) if out is None else out
+
+    if torch.cuda.current_device() == x.device.index:   # skip the device guard (several microseconds) when it is a no-op
+        launch()
+    else:
+        with torch.cuda.device(x.device):
+            launch()
+    if out is not None:
+        return out
+    return y if len(lead) == 1 else y.reshape(*lead, n)
+
+
+class PreparedMatmul:
+    """``ternary_matmul`` on fixed buffers with every check done once: ``p = PreparedMatmul(x, pw, scale, bias, clip)``,
+    then ``p()`` re-launches on the current stream reading ``x`` / writing ``p.out`` in place (update ``x`` with
+    ``copy_``).  For eager decode loops, where the per-call argument checks cost more than the kernel; a loop that
+    can be captured in a HIP graph does not need it."""
+
+    def __init__(self, x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias: Optional[torch.Tensor], clip_val: float,
+                 activation: Optional[str] = None, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None):
+        self.out = ternary_matmul(x, pw, scale, bias, clip_val, activation, out_dtype, out)   # validates, allocates, runs once
+        k, n = x.shape[-1], pw.shape[0]
+        x2 = x.reshape(-1, k)
+        if x2.data_ptr() != x.data_ptr() or (x2.shape[0] > 1 and x2.stride(0) < k) or (k > 1 and x2.stride(1) != 1):
+            raise ValueError("PreparedMatmul: x must be a dense [..., K] tensor (it is read in place on every call)")
+        y2 = self.out.reshape(-1, n)
+        self._scale = _vec(scale, n, x.device, "scale")
+        self._bias = _vec(bias, n, x.device, "bias") if bias is not None else None
+        self._keep = (x, pw, self.out)
+        self._device = x.device
+        self._shape = (_dt(x2, "x"), x2.shape[0], n, k)
+        self._args_head = (x2.data_ptr(), _dt(x2, "x"), x2.shape[0], k, _ld(x2), pw.data_ptr(), n, _ld(pw), self._scale.data_ptr(),
+                           self._bias.data_ptr() if self._bias is not None else None, float(clip_val), _ACTS[activation],
+                           y2.data_ptr(), _dt(y2, "out"), _ld(y2))
+
+    def __call__(self) -> torch.Tensor:
+        stream = int(torch.cuda.current_stream(self._device).cuda_stream)
+        ws_ptr, ws_bytes = _matmul_workspace(self._device, stream, *self._shape)
+        _check(_lib.tvl_ternary_matmul(*self._args_head, ws_ptr, ws_bytes, stream))
+        return self.out
 
 
 def _vec(v: torch.Tensor, n: int, device, name: str) -> torch.Tensor:
+    if (isinstance(v, torch.Tensor) and v.dtype == torch.float32 and v.dim() == 1 and v.shape[0] == n and v.device == device
+            and v.is_contiguous() and not v.requires_grad):
+        return v   # the common case, without building views
     v = _gpu(v, f"ternary_matmul({name})")
     if v.device != device:
         raise ValueError(f"ternary_matmul: {name} is on {v.device}, x on {device}")

@@ -254,3 +254,20 @@ def test_decode_harness_matches_dense_reference_and_graph_replay(dev):
         assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
     for a, b in zip(packed, replay):
         assert torch.equal(a, b)
+
+
+def test_prepared_matmul_matches_plain_call(dev):
+    import ternary_vllm_amd as tv
+    ops = tv.custom_ops_mod
+    torch.manual_seed(5)
+    for m, n, k in ((1, 256, 512), (40, 96, 128)):
+        x = torch.randn(m, k, device=dev).half()
+        pw = ops.ternarize_pack(torch.rand(n, k, device=dev) * 2 - 1)
+        scale, bias = torch.rand(n, device=dev) + 0.5, torch.randn(n, device=dev)
+        prep = ops.PreparedMatmul(x, pw, scale, bias, 100.0, activation="gelu_tanh")
+        want = ops.ternary_matmul(x, pw, scale, bias, 100.0, activation="gelu_tanh")
+        assert torch.equal(prep(), want)
+        x.copy_(torch.randn(m, k, device=dev).half())          # new activations in the same buffer
+        assert torch.equal(prep(), ops.ternary_matmul(x, pw, scale, bias, 100.0, activation="gelu_tanh"))
+    with pytest.raises(ValueError):
+        ops.PreparedMatmul(torch.randn(4, 64, device=dev).half()[:, ::2], pw[:, :8], scale, bias, 100.0)
