@@ -1,11 +1,12 @@
 """A/B the SAME library under two environments in one process is impossible (the switch is read once), so this runs
 the 4096^3 GEMM timing in two child processes alternately, several rounds each, and prints medians.
-    python tools/ab_env.py VAR [M N K]      (VAR unset vs VAR=1)"""
+    python tools/ab_env.py VAR[=VALUE] [M N K]      (VAR unset vs VAR=VALUE, default 1)"""
 import os
 import subprocess
 import sys
 
-var = sys.argv[1]
+var, _, val = sys.argv[1].partition("=")
+val = val or "1"
 shape = sys.argv[2:5] if len(sys.argv) >= 5 else ["4096", "4096", "4096"]
 child = r'''
 import os, sys, torch
@@ -35,7 +36,7 @@ for rnd in range(3):
         env = dict(os.environ)
         env.pop(var, None)
         if on:
-            env[var] = "1"
+            env[var] = val
         out = subprocess.run([sys.executable, "-c", child, *shape], env=env, capture_output=True, text=True, timeout=300)
         if out.returncode != 0:
             print(out.stderr[-2000:]); sys.exit(1)
@@ -43,5 +44,5 @@ for rnd in range(3):
 for on in (False, True):
     meds = sorted(float(r[0]) for r in res[on])
     flops = 2.0 * int(shape[0]) * int(shape[1]) * int(shape[2])
-    print(f"{var}={'1' if on else 'unset':5s}: median of process medians {meds[1]:7.2f} us  best {min(float(r[1]) for r in res[on]):7.2f} us -> "
+    print(f"{var}={val if on else 'unset':5s}: median of process medians {meds[1]:7.2f} us  best {min(float(r[1]) for r in res[on]):7.2f} us -> "
           f"{flops / meds[1] / 1e6:7.1f} TFLOP/s   checksum {res[on][0][2]}")
