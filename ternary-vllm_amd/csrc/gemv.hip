@@ -74,7 +74,7 @@ __device__ __forceinline__ void load_x32(const TX* p, XVec<TX>& v) {
     }
 }
 
-template <typename TX, typename TY, int CH, int ROWS, int WAVES>
+template <typename TX, typename TY, int CH, int ROWS, int WAVES, bool KSPLIT>
 __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw,
                                                           int n, int64_t ld_pw, const float* __restrict__ scale, const float* __restrict__ bias,
                                                           float clip, int act, TY* __restrict__ y, int64_t ld_y) {
@@ -84,8 +84,11 @@ __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__
     __syncthreads();
     const LutEntry<TX>* my_lut = lut[lane & 1];
 
-    const int ch0 = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * CH;   // wave-uniform
-    if (ch0 >= n) return;
+    // KSPLIT: the block's waves share CH channels and take k ranges 2048 * (wave + WAVES * i); otherwise each wave has
+    // its own CH channels and the whole k range
+    const int wave = threadIdx.x >> 6;
+    const int ch0 = KSPLIT ? blockIdx.x * CH : (blockIdx.x * WAVES + wave) * CH;   // wave-uniform
+    if (!KSPLIT && ch0 >= n) return;
     const uint8_t* wrow[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -98,7 +101,8 @@ __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__
 #pragma unroll
         for (int c = 0; c < CH; ++c) acc[r][c] = 0.0f;
 
-    for (int k0 = 32 * lane; k0 < k; k0 += 2048) {
+    const int kstart = (KSPLIT ? 2048 * wave : 0) + 32 * lane, kstride = KSPLIT ? 2048 * WAVES : 2048;
+    for (int k0 = kstart; k0 < k; k0 += kstride) {
         uint2 wq[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) wq[c] = *reinterpret_cast<const uint2*>(wrow[c] + (k0 - 32 * lane) / 4);
@@ -142,13 +146,29 @@ __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__
 
     const float cl = fabsf(clip);
     const bool has_bias = bias != nullptr;
+    __shared__ float part[KSPLIT ? WAVES : 1][ROWS * CH];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const float s = gv_wave_sum(acc[r][c]);
             const int ch = ch0 + c;
-            if (lane == 0 && r < m && ch < n)
+            if constexpr (KSPLIT) {
+                if (lane == 0) part[wave][r * CH + c] = s;
+            } else {
+                if (lane == 0 && r < m && ch < n)
+                    y[(int64_t)r * ld_y + ch] = from_float<TY>(epilogue_rt(s, scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl));
+            }
+        }
+    }
+    if constexpr (KSPLIT) {
+        __syncthreads();
+        if (threadIdx.x < ROWS * CH) {   // the waves' partial sums, added in wave order
+            const int r = threadIdx.x / CH, ch = ch0 + threadIdx.x % CH;
+            float s = part[0][threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) s += part[w][threadIdx.x];
+            if (r < m && ch < n)
                 y[(int64_t)r * ld_y + ch] = from_float<TY>(epilogue_rt(s, scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl));
         }
     }
@@ -172,24 +192,26 @@ bool gemv_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld
     return t_gemv <= t_other;
 }
 
-template <typename TX, typename TY, int CH, int WAVES>
+template <typename TX, typename TY, int CH, int WAVES, bool KSPLIT>
 static void launch_gemv_rows(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                              const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
-    const dim3 grid((unsigned)ceil_div(n, CH * WAVES)), block(64 * WAVES);
+    const dim3 grid((unsigned)ceil_div(n, KSPLIT ? CH : CH * WAVES)), block(64 * WAVES);
     if (m == 1)
-        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 1, WAVES>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
+        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 1, WAVES, KSPLIT>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
     else if (m == 2)
-        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 2, WAVES>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
+        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 2, WAVES, KSPLIT>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
     else
-        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 4, WAVES>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
+        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 4, WAVES, KSPLIT>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
 }
 
 template <typename TX, typename TY>
 static int launch_gemv_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                           const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
-    // few channels: 2 per wave so that the layer still makes >= 2 waves per SIMD; many: 8 per wave (activations reused)
-    if (n < 16384) launch_gemv_rows<TX, TY, 2, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
-    else launch_gemv_rows<TX, TY, 8, 1>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
+    // few channels: 2 per wave so that the layer still makes >= 2 waves per SIMD; many channels: 8 per wave (activations
+    // reused), and with a long k the block's 4 waves split it (4x the waves and the bytes in flight)
+    if (n < 16384) launch_gemv_rows<TX, TY, 2, 4, false>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
+    else if (k >= 8192) launch_gemv_rows<TX, TY, 8, 4, true>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
+    else launch_gemv_rows<TX, TY, 8, 1, false>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
     TVL_LAUNCH_CHECK();
     return TVL_OK;
 }

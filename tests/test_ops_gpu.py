@@ -193,7 +193,7 @@ SHAPES = [(1, 1, 1), (1, 8, 4), (3, 5, 7), (17, 33, 30), (64, 64, 64), (65, 130,
           (129, 129, 64), (200, 512, 1024), (745, 2048, 2048),
           (1, 128, 256), (1, 4096, 4096), (3, 200, 768), (16, 130, 512), (31, 6144, 2048), (32, 256, 1024), (8, 96, 3072),  # few rows:
           (2, 1000, 16384), (5, 129, 8192), (9, 64, 1280), (12, 520, 4352), (16, 2048, 8192), (1, 30, 32768),         # streaming kernels
-          (1, 7, 32), (2, 9, 96), (3, 130, 2080), (4, 2050, 2048), (1, 16390, 4096), (4, 16384, 160)]                 # single-launch decode kernel
+          (1, 7, 32), (2, 9, 96), (3, 130, 2080), (4, 2050, 2048), (1, 16390, 4096), (4, 16384, 160), (2, 16400, 8192), (3, 16385, 10240)]                 # single-launch decode kernel
 
 
 @pytest.mark.parametrize("m,n,k", SHAPES)
