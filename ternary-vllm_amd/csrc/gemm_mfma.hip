@@ -37,6 +37,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int BK = 64;             // k elements per pipeline step
 constexpr int ROW_BYTES = BK * 2;  // bytes of one activation row in the LDS tile
 constexpr int NBUF = 3;            // activation tiles in LDS
+constexpr int NUM_CUS = 256;       // MI355X compute units (the cost model and the persistent grid are sized for it)
 
 // ---- 2-bit -> f16 decode -------------------------------------------------------------------
 // Constants live in registers the compiler cannot see through (set once per kernel by inline asm),
@@ -388,7 +389,10 @@ __device__ __forceinline__ floatx4 mfma16(uint4 a, uint4 b, floatx4 c) {
     }
 }
 
-template <typename TX, typename TY, bool HAS_BIAS, int ACT, int WAVES_M>
+// PERSIST: the grid has fewer workgroups than tiles; workgroup b walks tiles b, b + gridDim.x, ... as ONE stream of k
+// steps: the loads of the next tile's first steps are issued during the current tile's last steps and its epilogue
+// (stores are asynchronous), so the per-tile launch / prologue / drain cost is paid once per workgroup, not per tile.
+template <typename TX, typename TY, bool HAS_BIAS, int ACT, int WAVES_M, bool PERSIST>
 __global__ void __launch_bounds__(512, 2)
 gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
                    const float* __restrict__ scale, const float* __restrict__ bias, float clip, TY* __restrict__ y,
@@ -406,22 +410,42 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     const int c = lane & 15, g = lane >> 4;
     const int wr = wid / WAVES_N, wc = wid % WAVES_N;
     const int q = (0x2130 >> (4 * g)) & 3;
-    const int tile = xcd_remap(blockIdx.x, nblk);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int nk = k / BK;
+    const int G = gridDim.x;
+    const int my_tiles = PERSIST ? (nblk - (int)blockIdx.x + G - 1) / G : 1;
+    const int total_steps = my_tiles * nk;
+    int vb_l = blockIdx.x, kb_l = 0;   // load cursor: tile (as a virtual block index) and k step the next loads fetch
+    int vb_c = blockIdx.x, kb_c = 0;   // the step being multiplied
+    int m0, n0;                        // origin of the tile being multiplied
+    {
+        const int tile = xcd_remap(vb_c, nblk);
+        m0 = (tile / tiles_n) * BM; n0 = (tile % tiles_n) * BN;
+    }
 
     const TX* a_src[ROUNDS];
+    const uint8_t* b_src[NTL];
+    auto set_load_tile = [&](int vb) __attribute__((always_inline)) {
+        const int tile = xcd_remap(vb, nblk);
+        const int lm0 = (tile / tiles_n) * BM, ln0 = (tile % tiles_n) * BN;
 #pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-        const int p = i * NT + tid;
-        const int row = p >> 3, cs = p & 7;
-        const int chunk = cs ^ ((row >> 1) & 7);
-        int gm = m0 + row;
-        gm = gm < m ? gm : m - 1;
-        a_src[i] = x + (int64_t)gm * ld_x + chunk * 8;
-    }
+        for (int i = 0; i < ROUNDS; ++i) {
+            const int p = i * NT + tid;
+            const int row = p >> 3, cs = p & 7;
+            const int chunk = cs ^ ((row >> 1) & 7);
+            int gm = lm0 + row;
+            gm = gm < m ? gm : m - 1;
+            a_src[i] = x + (int64_t)gm * ld_x + chunk * 8;
+        }
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            int gn = ln0 + wc * WN + t * 16 + c;
+            gn = gn < n ? gn : n - 1;
+            b_src[t] = pw + (int64_t)gn * ld_pw + 4 * q;
+        }
+    };
+    set_load_tile(vb_l);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
-    auto stage_a = [&](int kb, int buf) {
+    auto stage_a = [&](int kb, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + buf * A_TILE_BYTES + (i * NT + wid * 64) * 16);
@@ -432,20 +456,24 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         }
     };
 
-    const uint8_t* b_src[NTL];
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) {
-        int gn = n0 + wc * WN + t * 16 + c;
-        gn = gn < n ? gn : n - 1;
-        b_src[t] = pw + (int64_t)gn * ld_pw + 4 * q;
-    }
-    auto load_b = [&](int kb, uint32_t (&dst)[NTL]) {
+    auto load_b = [&](int kb, uint32_t (&dst)[NTL]) __attribute__((always_inline)) {
         int kw = kb;
         kw = kw >= w_steps ? kw - w_steps : kw;
         kw = kw >= w_steps ? kw - w_steps : kw;
 #pragma unroll
         for (int t = 0; t < NTL; ++t)
             asm volatile("global_load_dword %0, %1, off" : "=v"(dst[t]) : "v"(b_src[t] + (int64_t)kw * (BK / 4)) : "memory");
+    };
+    // fetch the cursor's step into LDS buffer `buf` / registers `w`, then advance the cursor (to the next tile of this
+    // workgroup after a tile's last step; past the very last step it stays there: harmless re-fetches into a buffer
+    // nobody reads again, so that the number of loads per step is constant)
+    auto issue_loads = [&](int buf, uint32_t (&w)[NTL]) __attribute__((always_inline)) {
+        stage_a(kb_l, buf);
+        load_b(kb_l, w);
+        if (++kb_l == nk) {
+            if (PERSIST && vb_l + G < nblk) { vb_l += G; kb_l = 0; set_load_tile(vb_l); }
+            else kb_l = nk - 1;
+        }
     };
     auto wait_loads = [&](uint32_t (&w)[NTL]) {
         if constexpr (NTL == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]) : : "memory");
@@ -465,13 +493,13 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         for (int t = 0; t < NTL; ++t) acc[i][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
     const DecodeConsts dc = make_decode_consts();
 
-    auto read_a = [&](int buf, int s, int half, uint4 (&af)[MH]) {
+    auto read_a = [&](int buf, int s, int half, uint4 (&af)[MH]) __attribute__((always_inline)) {
         const unsigned char* abase = lds + buf * A_TILE_BYTES + a_row_off + a_col_off[s] + half * MH * 16 * ROW_BYTES;
 #pragma unroll
         for (int i = 0; i < MH; ++i) af[i] = *reinterpret_cast<const uint4*>(abase + i * 16 * ROW_BYTES);
     };
     auto decode_b = [&](uint32_t d, int s) { return s ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc); };
-    auto mma = [&](const uint4 (&af)[MH], int half, const uint4 (&bf)[NTL]) {
+    auto mma = [&](const uint4 (&af)[MH], int half, const uint4 (&bf)[NTL]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MH; ++i)
 #pragma unroll
@@ -490,11 +518,74 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         }
     };
 
+    auto store_tile = [&]() __attribute__((always_inline)) {
+        // ---- epilogue: lane (c, g) owns activation row 16 i + c and channels 16 t + 4 g + e -------------------------------
+        // 16-bit outputs: v_permlane16_swap hands even lane groups their neighbour's 4 channels of tile 0 and odd lane
+        // groups their neighbour's 4 channels of tile 1, so every lane stores 16 contiguous bytes.
+        const float cl = fabsf(clip);
+        const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) | (uintptr_t)(ld_y * (int64_t)sizeof(TY))) & 15) == 0;
+        const int nb = n0 + wc * WN;
+        const int noff = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;   // first of the 8 channels a lane stores after the swap
+    #pragma unroll
+        for (int tp = 0; tp < NTL; tp += 2) {                  // pairs of 16-channel tiles
+            float sc[2][4], bi[2][4];
+    #pragma unroll
+            for (int t = 0; t < 2; ++t)
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gn = nb + 16 * (tp + t) + 4 * g + e;
+                    sc[t][e] = gn < n ? scale[gn] : 0.0f;
+                    bi[t][e] = (HAS_BIAS && gn < n) ? bias[gn] : 0.0f;
+                }
+    #pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int gm = m0 + wr * WM + 16 * i + c;
+                float v[2][4];
+    #pragma unroll
+                for (int t = 0; t < 2; ++t)
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) v[t][e] = epilogue<HAS_BIAS, ACT>(acc[i][tp + t][e], sc[t][e], bi[t][e], cl);
+                TY* yrow = y + (int64_t)(gm < m ? gm : 0) * ld_y;
+                if (vec_ok && nb + 16 * tp + 32 <= n) {
+                    if constexpr (sizeof(TY) == 4) {
+                        if (gm < m) {
+    #pragma unroll
+                            for (int t = 0; t < 2; ++t)
+                                *reinterpret_cast<float4*>(yrow + nb + 16 * (tp + t) + 4 * g) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
+                        }
+                    } else {
+                        uint2 pk[2];
+    #pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            TY tmp[4];
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e) tmp[e] = from_float<TY>(v[t][e]);
+                            pk[t] = *reinterpret_cast<const uint2*>(tmp);
+                        }
+                        // all 64 lanes take part in the swap (no divergence above this point)
+                        auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+                        auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+                        const uint4 out = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                        if (gm < m) *reinterpret_cast<uint4*>(yrow + nb + 16 * tp + noff) = out;
+                    }
+                } else if (gm < m) {
+    #pragma unroll
+                    for (int t = 0; t < 2; ++t)
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int gn = nb + 16 * (tp + t) + 4 * g + e;
+                            if (gn < n) yrow[gn] = from_float<TY>(v[t][e]);
+                        }
+                }
+            }
+        }
+    };
+
     uint32_t bq0[NTL], bq1[NTL], bq2[NTL];   // packed weights (16 per lane and tile) of steps 3j, 3j+1, 3j+2
     uint4 afA[MH], afB[MH], bf0[NTL], bf1[NTL];   // bf0 / bf1: decoded weights of MFMA group s = 0 / 1
     // one step = four phases (s, half of the 16 row tiles); each phase reads the NEXT phase's activation fragments
     // first, then interleaves its 16 MFMAs with the decode of one weight fragment needed two phases later
-    auto step = [&](int kb, auto buf_c, uint32_t (&w0)[NTL], uint32_t (&w1)[NTL], uint32_t (&w2)[NTL]) {
+    auto step = [&](auto buf_c, uint32_t (&w0)[NTL], uint32_t (&w1)[NTL], uint32_t (&w2)[NTL]) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_c)::value;
         constexpr int buf1 = (buf + 1) % NBUF, buf2 = (buf + 2) % NBUF;
         read_a(buf, 0, 1, afB);
@@ -510,9 +601,8 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         // ---- middle of the step: tile kb+1 (and its weights w1) complete, tile kb-1 retired ----
         wait_loads(w1);
         __builtin_amdgcn_s_barrier();
-        const int kn = kb + 2 < nk ? kb + 2 : nk - 1;
         read_a(buf, 1, 1, afB);
-        stage_a(kn, buf2); load_b(kn, w2);
+        issue_loads(buf2, w2);
         __builtin_amdgcn_sched_barrier(0);
         decode_part(w1, 0, 0, bf0); mma(afA, 0, bf1);
         interleave_hint();
@@ -522,11 +612,24 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         decode_part(w1, 0, 1, bf0); mma(afB, 1, bf1);
         interleave_hint();
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PERSIST) {
+            if (++kb_c == nk) {   // last step of a tile: write it out and start the next one (its first fragments are in afA / bf0)
+                store_tile();
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) acc[i][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                kb_c = 0;
+                vb_c += G;
+                const int tile = xcd_remap(vb_c < nblk ? vb_c : nblk - 1, nblk);
+                m0 = (tile / tiles_n) * BM; n0 = (tile % tiles_n) * BN;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     };
 
-    stage_a(0, 0);
-    load_b(0, bq0);
-    if (nk > 1) { stage_a(1, 1); load_b(1, bq1); }
+    issue_loads(0, bq0);
+    if (total_steps > 1) issue_loads(1, bq1);
     else {
 #pragma unroll
         for (int t = 0; t < NTL; ++t) bq1[t] = 0;
@@ -539,75 +642,15 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     read_a(0, 0, 0, afA);
     decode_part(bq0, 0, 0, bf0);
     decode_part(bq0, 0, 1, bf0);
-    for (int kb = 0; kb < nk; kb += NBUF) {
-        step(kb, std::integral_constant<int, 0>{}, bq0, bq1, bq2);
-        if (kb + 1 < nk) step(kb + 1, std::integral_constant<int, 1>{}, bq1, bq2, bq0);
-        if (kb + 2 < nk) step(kb + 2, std::integral_constant<int, 2>{}, bq2, bq0, bq1);
+    for (int gs = 0; gs < total_steps; gs += NBUF) {
+        step(std::integral_constant<int, 0>{}, bq0, bq1, bq2);
+        if (gs + 1 < total_steps) step(std::integral_constant<int, 1>{}, bq1, bq2, bq0);
+        if (gs + 2 < total_steps) step(std::integral_constant<int, 2>{}, bq2, bq0, bq1);
     }
     wait_loads(bq0);
     wait_loads(bq1);
     wait_loads(bq2);
-
-    // ---- epilogue: lane (c, g) owns activation row 16 i + c and channels 16 t + 4 g + e -------------------------------
-    // 16-bit outputs: v_permlane16_swap hands even lane groups their neighbour's 4 channels of tile 0 and odd lane
-    // groups their neighbour's 4 channels of tile 1, so every lane stores 16 contiguous bytes.
-    const float cl = fabsf(clip);
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) | (uintptr_t)(ld_y * (int64_t)sizeof(TY))) & 15) == 0;
-    const int nb = n0 + wc * WN;
-    const int noff = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;   // first of the 8 channels a lane stores after the swap
-#pragma unroll
-    for (int tp = 0; tp < NTL; tp += 2) {                  // pairs of 16-channel tiles
-        float sc[2][4], bi[2][4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int gn = nb + 16 * (tp + t) + 4 * g + e;
-                sc[t][e] = gn < n ? scale[gn] : 0.0f;
-                bi[t][e] = (HAS_BIAS && gn < n) ? bias[gn] : 0.0f;
-            }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int gm = m0 + wr * WM + 16 * i + c;
-            float v[2][4];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[t][e] = epilogue<HAS_BIAS, ACT>(acc[i][tp + t][e], sc[t][e], bi[t][e], cl);
-            TY* yrow = y + (int64_t)(gm < m ? gm : 0) * ld_y;
-            if (vec_ok && nb + 16 * tp + 32 <= n) {
-                if constexpr (sizeof(TY) == 4) {
-                    if (gm < m) {
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            *reinterpret_cast<float4*>(yrow + nb + 16 * (tp + t) + 4 * g) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
-                    }
-                } else {
-                    uint2 pk[2];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        TY tmp[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) tmp[e] = from_float<TY>(v[t][e]);
-                        pk[t] = *reinterpret_cast<const uint2*>(tmp);
-                    }
-                    // all 64 lanes take part in the swap (no divergence above this point)
-                    auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
-                    auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
-                    const uint4 out = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-                    if (gm < m) *reinterpret_cast<uint4*>(yrow + nb + 16 * tp + noff) = out;
-                }
-            } else if (gm < m) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int gn = nb + 16 * (tp + t) + 4 * g + e;
-                        if (gn < n) yrow[gn] = from_float<TY>(v[t][e]);
-                    }
-            }
-        }
-    }
+    if constexpr (!PERSIST) store_tile();
 }
 
 // Sum the split-K slabs in a fixed order (deterministic: slab 0, 1, 2, ...) and apply the fused epilogue.
@@ -688,10 +731,11 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
     do {                                                                                                           \
         if constexpr (BM == 256) {   /* the big tile runs on the 16x16x32 instruction */                            \
             /* 1 x 8 waves; the 2 x 4 layout (WAVES_M = 2: half the LDS reads, twice the weight decode) measured 21 % slower */ \
-            auto k16 = gemm_mfma16_kernel<TX, TY, HB, ACT, 1>;                                                     \
+            const bool persist = nblk > NUM_CUS;   /* more tiles than CUs: one workgroup per CU walks several (+2..7 %) */ \
+            auto k16 = persist ? gemm_mfma16_kernel<TX, TY, HB, ACT, 1, true> : gemm_mfma16_kernel<TX, TY, HB, ACT, 1, false>; \
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-            hipLaunchKernelGGL(k16, grid, block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, y, \
-                               ld_y, tiles_n, nblk, w_steps);                                                      \
+            hipLaunchKernelGGL(k16, dim3(persist ? NUM_CUS : nblk), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, \
+                               bias, clip, y, ld_y, tiles_n, nblk, w_steps);                                       \
             break;                                                                                                 \
         }                                                                                                          \
         auto kern = gemm_mfma_kernel<TX, TY, BM, BN, WAVES_M, WAVES_N, HB, ACT, false>;                             \

@@ -454,6 +454,28 @@ def test_popcount_invalid_code_and_gelu(ops, dev):
     assert np.max(np.abs(got.cpu().numpy() - want)) <= 1e-5
 
 
+@pytest.mark.parametrize("m,n,k", [(4400, 4200, 192), (5000, 4100, 64), (25216, 768, 128), (2600, 8192, 448)])
+@pytest.mark.parametrize("xdt", [torch.float16, torch.bfloat16, torch.float32])
+def test_matmul_more_tiles_than_cus(ops, dev, m, n, k, xdt):
+    """More 256 x 256 output tiles than compute units: one workgroup walks several tiles as one stream of k steps
+    (ragged edges, one to seven steps per tile).  Exact grid, so a float32 matmul of the unpacked weights gives the
+    same bits; a row sample is checked against the CPU oracle."""
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    x = torch.randint(-64, 65, (m, k), generator=g).float() / 64.0
+    w = torch.rand(n, k, generator=g) * 2 - 1
+    scale = torch.rand(n, generator=g) + 0.5
+    bias = torch.randn(n, generator=g)
+    pw = ops.ternarize_pack(w.to(dev))
+    y = ops.ternary_matmul(x.to(dev).to(xdt), pw, scale.to(dev), bias.to(dev), 100.0, out_dtype=torch.float32)
+    ref = torch.clip((x.to(dev) @ ops.unpack_ternary(pw, k).t()) * scale.to(dev) + bias.to(dev), -100.0, 100.0)
+    assert torch.equal(y, ref)
+    rows = torch.randint(0, m, (16,), generator=g)
+    want = O.ternary_matmul(x[rows].numpy(), pw.cpu().numpy(), scale.numpy(), bias.numpy(), 100.0)
+    assert np.array_equal(y[rows.to(dev)].cpu().numpy(), want)
+    y16 = ops.ternary_matmul(x.to(dev).half(), pw, scale.to(dev), bias.to(dev), 100.0)   # 16-byte store path
+    assert torch.equal(y16, ref.half())
+
+
 def test_ternary_mm(ops, dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "ternary_mm.npz"))
     for size in (32, 256):
