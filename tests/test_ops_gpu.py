@@ -476,6 +476,24 @@ def test_matmul_more_tiles_than_cus(ops, dev, m, n, k, xdt):
     assert torch.equal(y16, ref.half())
 
 
+@pytest.mark.parametrize("m,n,k", [(300, 512, 256), (2, 64, 64), (20, 100, 52), (4400, 4200, 64)])
+def test_matmul_nan_and_inf_like_torch_clip(ops, dev, m, n, k):
+    """NaN activations give NaN outputs (torch.clip keeps NaN, binary/modules.py:107), infinities clip to +-clip_val,
+    rows without them are untouched - on every kernel (small tiles, big tile, persistent, generic)."""
+    rng = np.random.default_rng(m + k)
+    x, pw, scale, b = _case(rng, m, n, k)
+    x[0, 3] = np.nan
+    x[1 % m, 5] = np.inf
+    xt = torch.from_numpy(x).to(dev).half()
+    wt = torch.from_numpy(O.unpack_format_c(pw, k)).to(dev)
+    ref = torch.clip((xt.float() @ wt.t()) * torch.from_numpy(scale).to(dev) + torch.from_numpy(b).to(dev), -100.0, 100.0)
+    got = ops.ternary_matmul(xt, torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev), torch.from_numpy(b).to(dev), 100.0,
+                             out_dtype=torch.float32)
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))
+    assert bool(torch.isnan(got[0]).any())
+    assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(ref, nan=7.0))
+
+
 def test_ternary_mm(ops, dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "ternary_mm.npz"))
     for size in (32, 256):
