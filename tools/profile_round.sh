@@ -11,13 +11,13 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
   timeout -s KILL 120 rocprofv3 --pmc $grp -d /tmp/pc_$tag -o pmc --output-format csv -- python3 $R/tools/run_gemm.py 4096 4096 4096 12 f16 > /dev/null 2>&1
   echo "== $grp" >> $O/gemm_4096_pmc_summary.txt
-  python3 $R/tools/pmc_summary.py gemm_mfma_kernel $(find /tmp/pc_$tag -name "*counter_collection.csv") >> $O/gemm_4096_pmc_summary.txt
+  python3 $R/tools/pmc_summary.py gemm_mfma16_kernel $(find /tmp/pc_$tag -name "*counter_collection.csv") >> $O/gemm_4096_pmc_summary.txt
 done
 # 3. traffic of the decode kernel (M=1, 16384^2) and the pack kernel
 for grp in "FETCH_SIZE" "WRITE_SIZE"; do
   timeout -s KILL 120 rocprofv3 --pmc $grp -d /tmp/pd_$grp -o pmc --output-format csv -- python3 $R/tools/run_shapes.py 1,16384,16384 > /dev/null 2>&1
   echo "== $grp (decode 1x16384x16384)" >> $O/decode_pmc_summary.txt
-  python3 $R/tools/pmc_summary.py gemm_stream_kernel $(find /tmp/pd_$grp -name "*counter_collection.csv") >> $O/decode_pmc_summary.txt
+  python3 $R/tools/pmc_summary.py gemv_kernel $(find /tmp/pd_$grp -name "*counter_collection.csv") >> $O/decode_pmc_summary.txt
 done
 cat $O/gemm_4096_pmc_summary.txt $O/decode_pmc_summary.txt
 head -12 $O/bench_kernel_stats.csv | cut -c1-180
