@@ -1,6 +1,6 @@
 // Shape-agnostic packed ternary matmul (any m, n, k, leading dimensions and alignment) and the
-// dense-weight select-and-sum op.  Correctness path for odd shapes and float32 activations; the
-// tuned MFMA / streaming kernels in gemm_mfma.hip and gemv_skinny.hip take the aligned cases.
+// dense-weight select-and-sum op.  The path for odd shapes and misaligned buffers; the tuned kernels in
+// gemm_mfma.hip, gemm_stream.hip, gemm_skinny.hip and gemv.hip take the aligned cases.
 //
 // y[m,n] = act(clip((sum_k x[m,k] * (code(pw[n,k]) - 1)) * scale[n] + bias[n]))
 // accumulated in float32: one fmaf per term inside each 32-deep k chunk, chunk sums added to the

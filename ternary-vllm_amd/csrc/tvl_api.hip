@@ -30,7 +30,8 @@ int tvl_version(void) { return TVL_VERSION; }
 const char* tvl_last_error(void) { return g_last_error.c_str(); }
 
 const char* tvl_build_info(void) {
-    return "libternary_hip: gfx950 (CDNA4) HIP kernels; packed ternary GEMM on v_mfma_f32_32x32x16_{f16,bf16}";
+    return "libternary_hip: gfx950 (CDNA4) HIP kernels; packed ternary GEMM on v_mfma_f32_16x16x32 / 32x32x16 {f16,bf16}, "
+           "table-lookup GEMV, AND+popcount path";
 }
 
 int tvl_quantize_pack(const void* w, int w_dtype, int64_t n, int64_t k, int64_t ld_w, int mode, float threshold, uint8_t* pw,
