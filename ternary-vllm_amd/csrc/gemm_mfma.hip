@@ -379,6 +379,7 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
 // That assignment of q keeps the swizzled ds_read_b128 fragment reads conflict-free: the two lane groups that share
 // an LDS cycle read chunk indices whose bits 1 and 2 have equal parity.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef uint32_t nts_u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename TX>
 __device__ __forceinline__ floatx4 mfma16(uint4 a, uint4 b, floatx4 c) {
@@ -551,7 +552,7 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
                         if (gm < m) {
     #pragma unroll
                             for (int t = 0; t < 2; ++t)
-                                *reinterpret_cast<float4*>(yrow + nb + 16 * (tp + t) + 4 * g) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
+                                __builtin_nontemporal_store((floatx4){v[t][0], v[t][1], v[t][2], v[t][3]}, reinterpret_cast<floatx4*>(yrow + nb + 16 * (tp + t) + 4 * g));
                         }
                     } else {
                         uint2 pk[2];
@@ -566,7 +567,8 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
                         auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
                         auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
                         const uint4 out = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-                        if (gm < m) *reinterpret_cast<uint4*>(yrow + nb + 16 * tp + noff) = out;
+                        // streaming (non-temporal) stores: the output is written once and is far larger than L2; +2..3 % by A/B
+                        if (gm < m) __builtin_nontemporal_store(__builtin_bit_cast(nts_u32x4, out), reinterpret_cast<nts_u32x4*>(yrow + nb + 16 * tp + noff));
                     }
                 } else if (gm < m) {
     #pragma unroll

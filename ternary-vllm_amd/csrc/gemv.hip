@@ -19,6 +19,7 @@ namespace tvl {
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t nt_u32x2 __attribute__((ext_vector_type(2)));
 
 // table entry of one packed byte: its four weights (code - 1; code 3 -> +2) in the multiply type
 template <typename TX> struct LutEntry { uint32_t w01, w23; };          // two pairs of f16 / bf16
@@ -105,7 +106,10 @@ __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__
     for (int k0 = kstart; k0 < k; k0 += kstride) {
         uint2 wq[CH];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) wq[c] = *reinterpret_cast<const uint2*>(wrow[c] + (k0 - 32 * lane) / 4);
+        for (int c = 0; c < CH; ++c) {   // once-read weight stream: non-temporal
+            const nt_u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x2*>(wrow[c] + (k0 - 32 * lane) / 4));
+            wq[c] = make_uint2(t[0], t[1]);
+        }
         XVec<TX> xv[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) load_x32<TX>(x + (int64_t)(r < m ? r : 0) * ld_x + k0, xv[r]);
