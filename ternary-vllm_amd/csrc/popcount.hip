@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(256) popcount_rows_kernel(const uint32_t* __re
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) p[r] = q[r] = 0;
     for (int w = lane; w < words; w += 64) {
-        const uint32_t pw_ = pos[ch * ld_planes + w], nw_ = neg[ch * ld_planes + w];
+        // once-read plane stream: non-temporal
+        const uint32_t pw_ = __builtin_nontemporal_load(pos + ch * ld_planes + w), nw_ = __builtin_nontemporal_load(neg + ch * ld_planes + w);
         cnt += __popc(pw_) - __popc(nw_);
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {

@@ -1,5 +1,5 @@
 """A/B several builds of libternary_hip.so on one ternary_matmul shape in ONE process.
-    python tools/ab_libs.py M N K libA.so libB.so [libC.so ...]
+    python tools/ab_libs.py M N K libA.so libB.so [libC.so ...]      (TVL_AB_DTYPE=f32|f16|bf16 picks the activation type)
 The packed weights rotate over buffers totalling > 512 MiB (more than the Infinity Cache), so every launch
 streams them from HBM.  Each sample times one sweep over all buffers between two events."""
 import ctypes
@@ -18,7 +18,8 @@ for lib in libs:
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 nb = max(2, min(64, (640 << 20) // (N * K // 4)))
-x = torch.randn(M, K, device=dev).half()
+XD = {"f32": (torch.float32, 0), "f16": (torch.float16, 1), "bf16": (torch.bfloat16, 2)}[os.environ.get("TVL_AB_DTYPE", "f16")]
+x = torch.randn(M, K, device=dev).to(XD[0])
 pws = [torch.randint(0, 171, (N, K // 4), dtype=torch.uint8, device=dev) for _ in range(nb)]
 scale = torch.rand(N, device=dev) + 0.5
 bias = torch.randn(N, device=dev)
@@ -28,7 +29,7 @@ stream = torch.cuda.current_stream().cuda_stream
 
 
 def launch(li, i):
-    rc = libs[li].tvl_ternary_matmul(x.data_ptr(), 1, M, K, 0, pws[i % nb].data_ptr(), N, 0, scale.data_ptr(), bias.data_ptr(), 100.0, 0,
+    rc = libs[li].tvl_ternary_matmul(x.data_ptr(), XD[1], M, K, 0, pws[i % nb].data_ptr(), N, 0, scale.data_ptr(), bias.data_ptr(), 100.0, 0,
                                      ys[li].data_ptr(), 1, 0, ws.data_ptr(), ws.numel(), stream)
     assert rc == 0
 
