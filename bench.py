@@ -286,7 +286,7 @@ def main():
         f_avg, _ = time_launches(lambda i: ops.ternary_matmul(xf, pw, scale, bias, 100.0, out=yf), 10, 3, rounds=3)
         extra["f32_activations"] = {"shape": [M, N, K], "avg_call_ms": round(f_avg, 4),
                                     "effective_TFLOPs": round(2.0 * M * N * K / (f_avg * 1e-3) / 1e12, 1),
-                                    "kernels": "tvl::split_f32_kernel + tvl::gemm_mfma_kernel<bf16> over 3K"}
+                                    "kernels": "tvl::split_f32_kernel + tvl::gemm_mfma16_kernel<bf16, f32> over 3K"}
         del xf, yf
 
         if args.sweep:
