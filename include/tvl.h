@@ -106,6 +106,15 @@ int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t
                        const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                        const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The same product for two Dense layers that read the same input and are stored as ONE packed matrix (their
+ * rows, scales and biases concatenated): channels [0, act_begin_channel) get no activation, channels
+ * [act_begin_channel, n) get `act`.  The reference's Phi block feeds one LayerNorm output to both Wqkv (linear) and
+ * fc1 (tanh-GELU) - impl/tf/moondream/layers.py:334-347 with the GELU folded into fc1 at utils/conversion.py:185-187 -
+ * so the two run as one launch over n = 6144 + 8192 channels.  act_begin_channel = 0 is tvl_ternary_matmul. */
+int tvl_ternary_matmul_act_from(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x,
+                                const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
+                                const float* bias, float clip, int act, int64_t act_begin_channel, void* y,
+                                int y_dtype, int64_t ld_y, void* workspace, size_t workspace_bytes, void* stream);
 size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k);
 size_t tvl_ternary_matmul_workspace_bytes_for(int x_dtype, int64_t m, int64_t n, int64_t k);
 

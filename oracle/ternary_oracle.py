@@ -195,7 +195,7 @@ def gelu_tanh(x: np.ndarray) -> np.ndarray:
 ACT_NONE, ACT_GELU_TANH = 0, 1
 
 
-def ternary_matmul(x, pw, scale, bias, clip_val, k=None, act=ACT_NONE, acc_dtype=np.float64, out_dtype=np.float32):
+def ternary_matmul(x, pw, scale, bias, clip_val, k=None, act=ACT_NONE, acc_dtype=np.float64, out_dtype=np.float32, act_begin=0):
     """``clip((x @ unpack(pw)^T) * scale + bias, +-clip)`` then optional activation.
 
     Order of operations follows ``binary/modules.py:101-109`` (matmul, ``*= scale``,
@@ -207,6 +207,9 @@ def ternary_matmul(x, pw, scale, bias, clip_val, k=None, act=ACT_NONE, acc_dtype
     random data; for inputs on a dyadic grid float32 is already exact); the
     epilogue multiply, add and clip are done in float32 - two roundings, no fused
     multiply-add - exactly like the reference's separate ``*=`` and ``+=``.
+
+    ``act_begin``: only output channels ``>= act_begin`` get the activation (two layers that share
+    their input, ``impl/tf/moondream/layers.py:334-347``, stored as one packed matrix).
     """
     x = np.asarray(x)
     kk = x.shape[-1] if k is None else k
@@ -219,7 +222,7 @@ def ternary_matmul(x, pw, scale, bias, clip_val, k=None, act=ACT_NONE, acc_dtype
     c = np.float32(abs(clip_val))
     y = np.clip(y, -c, c)
     if act == ACT_GELU_TANH:
-        y = gelu_tanh(y).astype(np.float32)
+        y[:, act_begin:] = gelu_tanh(y[:, act_begin:]).astype(np.float32)
     return y.reshape(x.shape[:-1] + (w.shape[0],)).astype(out_dtype)
 
 

@@ -17,7 +17,7 @@ template <typename TX, typename TY, bool HAS_BIAS, int ACT>
 __global__ void __launch_bounds__(256) gemm_generic_kernel(const TX* __restrict__ x, int64_t m, int64_t k, int64_t ld_x,
                                                            const uint8_t* __restrict__ pw, int64_t n, int64_t ld_pw,
                                                            const float* __restrict__ scale, const float* __restrict__ bias,
-                                                           float clip, TY* __restrict__ y, int64_t ld_y) {
+                                                           float clip, int act_begin, TY* __restrict__ y, int64_t ld_y) {
     __shared__ float xs[GK][GT + 1];  // [k][m] : thread reads 4 rows at fixed k -> stride-1 over ty*4+i
     __shared__ float ws[GK][GT + 1];  // [k][n]
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -69,17 +69,17 @@ __global__ void __launch_bounds__(256) gemm_generic_kernel(const TX* __restrict_
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t mm = m0 + ty * 4 + i;
-            if (mm < m) y[mm * ld_y + nn] = from_float<TY>(epilogue<HAS_BIAS, ACT>(acc[i][j], s, b, c));
+            if (mm < m) y[mm * ld_y + nn] = from_float<TY>(epilogue_ch<HAS_BIAS, ACT>(acc[i][j], s, b, c, (int)nn, act_begin));
         }
     }
 }
 
 template <typename TX, typename TY>
 static int launch_generic_t(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                            const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
+                            const float* scale, const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, hipStream_t st) {
     const dim3 grid((unsigned)ceil_div(n, GT), (unsigned)ceil_div(m, GT)), block(256);
 #define TVL_GG(HB, ACT) \
-    hipLaunchKernelGGL((gemm_generic_kernel<TX, TY, HB, ACT>), grid, block, 0, st, x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, y, ld_y)
+    hipLaunchKernelGGL((gemm_generic_kernel<TX, TY, HB, ACT>), grid, block, 0, st, x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act_begin, y, ld_y)
     if (bias) {
         if (act == TVL_ACT_GELU_TANH) TVL_GG(true, TVL_ACT_GELU_TANH); else TVL_GG(true, TVL_ACT_NONE);
     } else {
@@ -92,24 +92,24 @@ static int launch_generic_t(const TX* x, int64_t m, int64_t k, int64_t ld_x, con
 
 template <typename TX>
 static int launch_generic_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                            const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y,
+                            const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y,
                             hipStream_t st) {
     switch (y_dtype) {
-        case TVL_F32: return launch_generic_t(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (float*)y, ld_y, st);
-        case TVL_F16: return launch_generic_t(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (f16*)y, ld_y, st);
-        case TVL_BF16: return launch_generic_t(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (bf16_t*)y, ld_y, st);
+        case TVL_F32: return launch_generic_t(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (float*)y, ld_y, st);
+        case TVL_F16: return launch_generic_t(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (f16*)y, ld_y, st);
+        case TVL_BF16: return launch_generic_t(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (bf16_t*)y, ld_y, st);
         default: set_error("ternary_matmul: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
     }
 }
 
 int launch_gemm_generic(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
-                        int64_t ld_pw, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype,
+                        int64_t ld_pw, const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype,
                         int64_t ld_y, hipStream_t st) {
     if (ceil_div(m, GT) > 65535) { set_error("ternary_matmul: m = %lld too large for the generic kernel", (long long)m); return TVL_ERR_INVALID; }
     switch (x_dtype) {
-        case TVL_F32: return launch_generic_x((const float*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
-        case TVL_F16: return launch_generic_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
-        case TVL_BF16: return launch_generic_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
+        case TVL_F32: return launch_generic_x((const float*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+        case TVL_F16: return launch_generic_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+        case TVL_BF16: return launch_generic_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
         default: set_error("ternary_matmul: unsupported activation dtype %d", x_dtype); return TVL_ERR_INVALID;
     }
 }

@@ -109,7 +109,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 template <typename TX, typename TY, int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_BIAS, int ACT, bool SPLIT>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
 gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
-                 const float* __restrict__ scale, const float* __restrict__ bias, float clip, TY* __restrict__ y,
+                 const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act_begin, TY* __restrict__ y,
                  int64_t ld_y, int tiles_n, int nblk, int steps_per_split, int w_steps) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
@@ -327,7 +327,8 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
             const int gm = m0 + wr * WM + i * 32 + r;
             float v[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = SPLIT ? acc[i][t][e] : epilogue<HAS_BIAS, ACT>(acc[i][t][e], sc[e], bi[e], c);
+            for (int e = 0; e < 16; ++e)
+                v[e] = SPLIT ? acc[i][t][e] : epilogue_ch<HAS_BIAS, ACT>(acc[i][t][e], sc[e], bi[e], c, nb + (e & 3) + 8 * (e >> 2) + 4 * h, act_begin);
             TY* yrow = y + (int64_t)(gm < m ? gm : 0) * ld_y;
             if (vec_ok && nb + 32 <= n) {
                 if (gm < m) {
@@ -396,7 +397,7 @@ __device__ __forceinline__ floatx4 mfma16(uint4 a, uint4 b, floatx4 c) {
 template <typename TX, typename TY, bool HAS_BIAS, int ACT, int WAVES_M, bool PERSIST>
 __global__ void __launch_bounds__(512, 2)
 gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
-                   const float* __restrict__ scale, const float* __restrict__ bias, float clip, TY* __restrict__ y,
+                   const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act_begin, TY* __restrict__ y,
                    int64_t ld_y, int tiles_n, int nblk, int w_steps) {
     constexpr int BM = 256, BN = 256, NT = 512;
     constexpr int WAVES_N = 8 / WAVES_M;
@@ -545,7 +546,8 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     #pragma unroll
                 for (int t = 0; t < 2; ++t)
     #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[t][e] = epilogue<HAS_BIAS, ACT>(acc[i][tp + t][e], sc[t][e], bi[t][e], cl);
+                    for (int e = 0; e < 4; ++e)
+                        v[t][e] = epilogue_ch<HAS_BIAS, ACT>(acc[i][tp + t][e], sc[t][e], bi[t][e], cl, nb + 16 * (tp + t) + 4 * g + e, act_begin);
                 TY* yrow = y + (int64_t)(gm < m ? gm : 0) * ld_y;
                 if (vec_ok && nb + 16 * tp + 32 <= n) {
                     if constexpr (sizeof(TY) == 4) {
@@ -661,7 +663,7 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
 template <typename TY, bool HAS_BIAS, int ACT>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t m, int64_t n,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
-                                                            float clip, TY* __restrict__ y, int64_t ld_y) {
+                                                            float clip, int act_begin, TY* __restrict__ y, int64_t ld_y) {
     const float c = fabsf(clip);
     const int64_t total = m * n, stride = m * n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -677,17 +679,17 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
             for (int u = 0; u < 8; ++u) acc += v[u];
         }
         for (; s < splits; ++s) acc += p[(int64_t)s * stride];
-        y[r * ld_y + col] = from_float<TY>(epilogue<HAS_BIAS, ACT>(acc, scale[col], HAS_BIAS ? bias[col] : 0.0f, c));
+        y[r * ld_y + col] = from_float<TY>(epilogue_ch<HAS_BIAS, ACT>(acc, scale[col], HAS_BIAS ? bias[col] : 0.0f, c, (int)col, act_begin));
     }
 }
 
 template <typename TY>
 static int launch_reduce(const float* slab, int splits, int64_t m, int64_t n, const float* scale, const float* bias, float clip,
-                         int act, TY* y, int64_t ld_y, hipStream_t st) {
+                         int act, int act_begin, TY* y, int64_t ld_y, hipStream_t st) {
     int64_t g = ceil_div(m * n, 256);
     g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
     const dim3 grid((unsigned)g), block(256);
-#define TVL_RD(HB, ACT) hipLaunchKernelGGL((splitk_reduce_kernel<TY, HB, ACT>), grid, block, 0, st, slab, splits, m, n, scale, bias, clip, y, ld_y)
+#define TVL_RD(HB, ACT) hipLaunchKernelGGL((splitk_reduce_kernel<TY, HB, ACT>), grid, block, 0, st, slab, splits, m, n, scale, bias, clip, act_begin, y, ld_y)
     if (bias) {
         if (act == TVL_ACT_GELU_TANH) TVL_RD(true, TVL_ACT_GELU_TANH); else TVL_RD(true, TVL_ACT_NONE);
     } else {
@@ -699,18 +701,18 @@ static int launch_reduce(const float* slab, int splits, int64_t m, int64_t n, co
 }
 
 int launch_splitk_reduce(const float* slab, int splits, int64_t m, int64_t n, const float* scale, const float* bias, float clip,
-                         int act, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
+                         int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
     switch (y_dtype) {
-        case TVL_F32: return launch_reduce<float>(slab, splits, m, n, scale, bias, clip, act, (float*)y, ld_y, st);
-        case TVL_F16: return launch_reduce<f16>(slab, splits, m, n, scale, bias, clip, act, (f16*)y, ld_y, st);
-        case TVL_BF16: return launch_reduce<bf16_t>(slab, splits, m, n, scale, bias, clip, act, (bf16_t*)y, ld_y, st);
+        case TVL_F32: return launch_reduce<float>(slab, splits, m, n, scale, bias, clip, act, act_begin, (float*)y, ld_y, st);
+        case TVL_F16: return launch_reduce<f16>(slab, splits, m, n, scale, bias, clip, act, act_begin, (f16*)y, ld_y, st);
+        case TVL_BF16: return launch_reduce<bf16_t>(slab, splits, m, n, scale, bias, clip, act, act_begin, (bf16_t*)y, ld_y, st);
         default: set_error("splitk_reduce: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
     }
 }
 
 template <typename TX, typename TY, int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                      const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, int splits, float* slab,
+                      const float* scale, const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, int splits, float* slab,
                       int w_steps, hipStream_t st) {
     const int tiles_m = (int)ceil_div(m, BM), tiles_n = (int)ceil_div(n, BN);
     const int nblk = tiles_m * tiles_n;
@@ -724,9 +726,9 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
         if (lds_bytes > 48 * 1024)
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(kern, dim3(nblk, splits), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip,
-                           slab, n, tiles_n, nblk, steps_per_split, w_steps);
+                           0, slab, n, tiles_n, nblk, steps_per_split, w_steps);
         TVL_LAUNCH_CHECK();
-        return launch_reduce<TY>(slab, splits, m, n, scale, bias, clip, act, y, ld_y, st);
+        return launch_reduce<TY>(slab, splits, m, n, scale, bias, clip, act, act_begin, y, ld_y, st);
     }
     const dim3 grid(nblk);
 #define TVL_GM(HB, ACT)                                                                                            \
@@ -737,14 +739,14 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
             auto k16 = persist ? gemm_mfma16_kernel<TX, TY, HB, ACT, 1, true> : gemm_mfma16_kernel<TX, TY, HB, ACT, 1, false>; \
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
             hipLaunchKernelGGL(k16, dim3(persist ? NUM_CUS : nblk), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, \
-                               bias, clip, y, ld_y, tiles_n, nblk, w_steps);                                       \
+                               bias, clip, act_begin, y, ld_y, tiles_n, nblk, w_steps);                            \
             break;                                                                                                 \
         }                                                                                                          \
         auto kern = gemm_mfma_kernel<TX, TY, BM, BN, WAVES_M, WAVES_N, HB, ACT, false>;                             \
         if (lds_bytes > 48 * 1024)                                                                                 \
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-        hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, y, \
-                           ld_y, tiles_n, nblk, 0, w_steps);                                                       \
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act_begin, \
+                           y, ld_y, tiles_n, nblk, 0, w_steps);                                                    \
     } while (0)
     if (bias) {
         if (act == TVL_ACT_GELU_TANH) TVL_GM(true, TVL_ACT_GELU_TANH); else TVL_GM(true, TVL_ACT_NONE);
@@ -795,28 +797,28 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_byte
 
 template <typename TX, typename TY>
 static int launch_mfma_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                          const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, void* workspace,
+                          const float* scale, const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, void* workspace,
                           size_t workspace_bytes, int w_steps, hipStream_t st) {
     const bool ws_ok = workspace != nullptr && aligned(workspace, 16);
     const GemmPlan p = plan_gemm(m, n, k, ws_ok ? workspace_bytes : 0);
     float* slab = (float*)workspace;
     if (p.bm == 256)
-        return launch_cfg<TX, TY, 256, 256, 1, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, 1, slab, w_steps, st);
+        return launch_cfg<TX, TY, 256, 256, 1, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, 1, slab, w_steps, st);
     if (p.bm == 128)
-        return launch_cfg<TX, TY, 128, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, w_steps, st);
+        return launch_cfg<TX, TY, 128, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, slab, w_steps, st);
     if (p.bm == 64)
-        return launch_cfg<TX, TY, 64, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, w_steps, st);
-    return launch_cfg<TX, TY, 32, 128, 1, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, slab, w_steps, st);
+        return launch_cfg<TX, TY, 64, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, slab, w_steps, st);
+    return launch_cfg<TX, TY, 32, 128, 1, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, slab, w_steps, st);
 }
 
 template <typename TX>
 static int launch_mfma_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                         const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y,
+                         const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y,
                          void* ws, size_t ws_bytes, int w_steps, hipStream_t st) {
     switch (y_dtype) {
-        case TVL_F32: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (float*)y, ld_y, ws, ws_bytes, w_steps, st);
-        case TVL_F16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (f16*)y, ld_y, ws, ws_bytes, w_steps, st);
-        case TVL_BF16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (bf16_t*)y, ld_y, ws, ws_bytes, w_steps, st);
+        case TVL_F32: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (float*)y, ld_y, ws, ws_bytes, w_steps, st);
+        case TVL_F16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (f16*)y, ld_y, ws, ws_bytes, w_steps, st);
+        case TVL_BF16: return launch_mfma_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (bf16_t*)y, ld_y, ws, ws_bytes, w_steps, st);
         default: set_error("ternary_matmul: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
     }
 }
@@ -881,7 +883,7 @@ bool gemm_mfma_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64
 }
 
 int launch_gemm_mfma(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
-                     int64_t ld_pw, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype,
+                     int64_t ld_pw, const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype,
                      int64_t ld_y, void* workspace, size_t workspace_bytes, hipStream_t st) {
     const int w_steps = (int)(k / BK);
     if (x_dtype == TVL_F32) {
@@ -891,12 +893,12 @@ int launch_gemm_mfma(const void* x, int x_dtype, int64_t m, int64_t k, int64_t l
         hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)x, m, k, ld_x, xs);
         TVL_LAUNCH_CHECK();
         const size_t used = split_bytes(m, k);
-        return launch_mfma_x((const bf16_t*)xs, m, 3 * k, 3 * k, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y,
+        return launch_mfma_x((const bf16_t*)xs, m, 3 * k, 3 * k, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y,
                              (char*)workspace + used, workspace_bytes - used, w_steps, st);
     }
     if (x_dtype == TVL_F16)
-        return launch_mfma_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, w_steps, st);
-    return launch_mfma_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, w_steps, st);
+        return launch_mfma_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, w_steps, st);
+    return launch_mfma_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, w_steps, st);
 }
 
 }  // namespace tvl

@@ -66,8 +66,8 @@ __device__ __forceinline__ floatx16 sk_mfma(uint4 a, uint4 b, floatx16 c) {
 template <typename TX, typename TY, int BKS, int ROWS, bool HAS_BIAS, int ACT, bool SPLIT>
 __global__ void __launch_bounds__(256, ROWS <= 8 ? 4 : 2)
 gemm_skinny_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
-                   const float* __restrict__ scale, const float* __restrict__ bias, float clip, TY* __restrict__ y, int64_t ld_y,
-                   int ss_per_split) {
+                   const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act_begin, TY* __restrict__ y,
+                   int64_t ld_y, int ss_per_split) {
     constexpr int ROWB = BKS * 2;          // bytes of one activation row in the LDS image
     constexpr int CPR = BKS / 8;           // 16-byte chunks per row
     constexpr int TILE_BYTES = ROWS * ROWB;  // ROWS activation rows (m <= ROWS); fragment reads of rows >= ROWS wrap around
@@ -187,7 +187,7 @@ gemm_skinny_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     for (int e = 0; e < 16; ++e) {
         const int cn = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if constexpr (SPLIT) v[e] = acc[e];
-        else v[e] = epilogue<HAS_BIAS, ACT>(acc[e], cn < n ? scale[cn] : 0.0f, (HAS_BIAS && cn < n) ? bias[cn] : 0.0f, c);
+        else v[e] = epilogue_ch<HAS_BIAS, ACT>(acc[e], cn < n ? scale[cn] : 0.0f, (HAS_BIAS && cn < n) ? bias[cn] : 0.0f, c, cn, act_begin);
     }
     if (r < m) {
         TY* yrow = y + (int64_t)r * ld_y;
@@ -245,7 +245,7 @@ size_t gemm_skinny_workspace_bytes(int64_t m, int64_t n, int64_t k) {
 
 template <typename TX, typename TY, int BKS, int ROWS>
 static int launch_skinny_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                             const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, int splits, float* slab,
+                             const float* scale, const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, int splits, float* slab,
                              hipStream_t st) {
     const int nblk = (int)ceil_div(n, 128);
     const size_t lds_bytes = 2 * ROWS * BKS * 2;
@@ -258,16 +258,16 @@ static int launch_skinny_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, co
         if (lds_bytes > 48 * 1024)
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(kern, dim3(nblk, splits), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip,
-                           slab, n, per);
+                           0, slab, n, per);
         TVL_LAUNCH_CHECK();
-        return launch_splitk_reduce(slab, splits, m, n, scale, bias, clip, act, y, std::is_same<TY, float>::value ? TVL_F32 : (std::is_same<TY, f16>::value ? TVL_F16 : TVL_BF16), ld_y, st);
+        return launch_splitk_reduce(slab, splits, m, n, scale, bias, clip, act, act_begin, y, std::is_same<TY, float>::value ? TVL_F32 : (std::is_same<TY, f16>::value ? TVL_F16 : TVL_BF16), ld_y, st);
     }
 #define TVL_SK(HB, ACT)                                                                                            \
     do {                                                                                                           \
         auto kern = gemm_skinny_kernel<TX, TY, BKS, ROWS, HB, ACT, false>;                                                \
         if (lds_bytes > 48 * 1024)                                                                                 \
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-        hipLaunchKernelGGL(kern, dim3(nblk, 1), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, y, ld_y, 0); \
+        hipLaunchKernelGGL(kern, dim3(nblk, 1), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act_begin, y, ld_y, 0); \
     } while (0)
     if (bias) {
         if (act == TVL_ACT_GELU_TANH) TVL_SK(true, TVL_ACT_GELU_TANH); else TVL_SK(true, TVL_ACT_NONE);
@@ -281,38 +281,38 @@ static int launch_skinny_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, co
 
 template <typename TX, typename TY>
 static int launch_skinny_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                            const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, void* ws, size_t ws_bytes,
+                            const float* scale, const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, void* ws, size_t ws_bytes,
                             hipStream_t st) {
     const bool ws_ok = ws != nullptr && aligned(ws, 16);
     const SkinnyPlan p = plan_skinny(m, n, k, ws_ok ? ws_bytes : 0);
     if (m <= 8) {
         if (p.bks == 512)
-            return launch_skinny_cfg<TX, TY, 512, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, (float*)ws, st);
-        return launch_skinny_cfg<TX, TY, 256, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, (float*)ws, st);
+            return launch_skinny_cfg<TX, TY, 512, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, (float*)ws, st);
+        return launch_skinny_cfg<TX, TY, 256, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, (float*)ws, st);
     }
     if (p.bks == 512)
-        return launch_skinny_cfg<TX, TY, 512, 32>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, (float*)ws, st);
-    return launch_skinny_cfg<TX, TY, 256, 32>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p.splits, (float*)ws, st);
+        return launch_skinny_cfg<TX, TY, 512, 32>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, (float*)ws, st);
+    return launch_skinny_cfg<TX, TY, 256, 32>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, (float*)ws, st);
 }
 
 template <typename TX>
 static int launch_skinny_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                           const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, void* ws,
+                           const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, void* ws,
                            size_t ws_bytes, hipStream_t st) {
     switch (y_dtype) {
-        case TVL_F32: return launch_skinny_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (float*)y, ld_y, ws, ws_bytes, st);
-        case TVL_F16: return launch_skinny_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (f16*)y, ld_y, ws, ws_bytes, st);
-        case TVL_BF16: return launch_skinny_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (bf16_t*)y, ld_y, ws, ws_bytes, st);
+        case TVL_F32: return launch_skinny_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (float*)y, ld_y, ws, ws_bytes, st);
+        case TVL_F16: return launch_skinny_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (f16*)y, ld_y, ws, ws_bytes, st);
+        case TVL_BF16: return launch_skinny_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (bf16_t*)y, ld_y, ws, ws_bytes, st);
         default: set_error("ternary_matmul: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
     }
 }
 
 int launch_gemm_skinny(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                       const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, void* workspace,
+                       const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, void* workspace,
                        size_t workspace_bytes, hipStream_t st) {
     if (x_dtype == TVL_F16)
-        return launch_skinny_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
-    return launch_skinny_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
+        return launch_skinny_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
+    return launch_skinny_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
 }
 
 }  // namespace tvl

@@ -51,7 +51,7 @@ constexpr int STREAM_DEPTH = 4;                 // steps of weights in flight pe
 template <typename TY, int TILES, int RA, int D, bool SPLIT>
 __global__ void __launch_bounds__(256, 2)
 gemm_stream_kernel(const f16* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
-                   const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act, TY* __restrict__ y, int64_t ld_y,
+                   const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act, int act_begin, TY* __restrict__ y, int64_t ld_y,
                    int steps_per_split, float* __restrict__ slab) {
     constexpr int RING = D + 1;                       // ring slots (steps) per wave
     constexpr int WRING = RING * TILES * 1024;        // bytes of one wave's weight ring
@@ -215,7 +215,7 @@ gemm_stream_kernel(const f16* __restrict__ x, int m, int k, int64_t ld_x, const 
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                o[e] = epilogue_rt(v[t][e], cn + e < n ? scale[cn + e] : 0.0f, (has_bias && cn + e < n) ? bias[cn + e] : 0.0f, has_bias, act, cl);
+                o[e] = epilogue_rt(v[t][e], cn + e < n ? scale[cn + e] : 0.0f, (has_bias && cn + e < n) ? bias[cn + e] : 0.0f, has_bias, act, cl, cn + e, act_begin);
             if (c < m) {
                 TY* yrow = y + (int64_t)c * ld_y;
                 if (vec_ok && cn + 4 <= n) {
@@ -303,7 +303,7 @@ size_t gemm_stream_workspace_bytes(int64_t m, int64_t n, int64_t k) {
 
 template <typename TY, int RA>
 static int launch_stream_cfg(const f16* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                             const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, const StreamPlan& p,
+                             const float* scale, const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, const StreamPlan& p,
                              unsigned char* ws, hipStream_t st) {
     constexpr int TILES = 2, D = STREAM_DEPTH;
     const int nblk = (int)ceil_div(n, 64 * TILES);
@@ -313,16 +313,16 @@ static int launch_stream_cfg(const f16* x, int64_t m, int64_t k, int64_t ld_x, c
         auto kern = gemm_stream_kernel<TY, TILES, RA, D, true>;
         if (lds_bytes > 48 * 1024)
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(kern, dim3(nblk, p.splits), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act,
+        hipLaunchKernelGGL(kern, dim3(nblk, p.splits), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, act_begin,
                            y, ld_y, p.per, reinterpret_cast<float*>(ws));
         TVL_LAUNCH_CHECK();
-        return launch_splitk_reduce(reinterpret_cast<const float*>(ws), p.splits, m, n, scale, bias, clip, act, y,
+        return launch_splitk_reduce(reinterpret_cast<const float*>(ws), p.splits, m, n, scale, bias, clip, act, act_begin, y,
                                     std::is_same<TY, float>::value ? TVL_F32 : (std::is_same<TY, f16>::value ? TVL_F16 : TVL_BF16), ld_y, st);
     } else {
         auto kern = gemm_stream_kernel<TY, TILES, RA, D, false>;
         if (lds_bytes > 48 * 1024)
             TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(kern, dim3(nblk, 1), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act,
+        hipLaunchKernelGGL(kern, dim3(nblk, 1), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, act_begin,
                            y, ld_y, 0, (float*)nullptr);
     }
     TVL_LAUNCH_CHECK();
@@ -331,25 +331,25 @@ static int launch_stream_cfg(const f16* x, int64_t m, int64_t k, int64_t ld_x, c
 
 template <typename TY>
 static int launch_stream_y(const f16* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                           const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, void* ws, size_t ws_bytes,
+                           const float* scale, const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, void* ws, size_t ws_bytes,
                            hipStream_t st) {
     const bool ws_ok = ws != nullptr && aligned(ws, 16);
     const StreamPlan p = plan_stream(m, n, k, ws_ok ? ws_bytes : 0);
-    if (p.ra == 1) return launch_stream_cfg<TY, 1>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p, (unsigned char*)ws, st);
-    if (p.ra == 2) return launch_stream_cfg<TY, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p, (unsigned char*)ws, st);
-    if (p.ra == 4) return launch_stream_cfg<TY, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p, (unsigned char*)ws, st);
-    if (p.ra == 8) return launch_stream_cfg<TY, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p, (unsigned char*)ws, st);
-    return launch_stream_cfg<TY, 16>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, p, (unsigned char*)ws, st);
+    if (p.ra == 1) return launch_stream_cfg<TY, 1>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p, (unsigned char*)ws, st);
+    if (p.ra == 2) return launch_stream_cfg<TY, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p, (unsigned char*)ws, st);
+    if (p.ra == 4) return launch_stream_cfg<TY, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p, (unsigned char*)ws, st);
+    if (p.ra == 8) return launch_stream_cfg<TY, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p, (unsigned char*)ws, st);
+    return launch_stream_cfg<TY, 16>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p, (unsigned char*)ws, st);
 }
 
 int launch_gemm_stream(const void* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                       const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, void* workspace,
+                       const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, void* workspace,
                        size_t workspace_bytes, hipStream_t st) {
     const f16* xh = (const f16*)x;
     switch (y_dtype) {
-        case TVL_F32: return launch_stream_y(xh, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (float*)y, ld_y, workspace, workspace_bytes, st);
-        case TVL_F16: return launch_stream_y(xh, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (f16*)y, ld_y, workspace, workspace_bytes, st);
-        case TVL_BF16: return launch_stream_y(xh, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (bf16_t*)y, ld_y, workspace, workspace_bytes, st);
+        case TVL_F32: return launch_stream_y(xh, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (float*)y, ld_y, workspace, workspace_bytes, st);
+        case TVL_F16: return launch_stream_y(xh, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (f16*)y, ld_y, workspace, workspace_bytes, st);
+        case TVL_BF16: return launch_stream_y(xh, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (bf16_t*)y, ld_y, workspace, workspace_bytes, st);
         default: set_error("ternary_matmul: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
     }
 }

@@ -78,7 +78,7 @@ __device__ __forceinline__ void load_x32(const TX* p, XVec<TX>& v) {
 template <typename TX, typename TY, int CH, int ROWS, int WAVES, bool KSPLIT>
 __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw,
                                                           int n, int64_t ld_pw, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                          float clip, int act, TY* __restrict__ y, int64_t ld_y) {
+                                                          float clip, int act, int act_begin, TY* __restrict__ y, int64_t ld_y) {
     __shared__ LutEntry<TX> lut[2][256];
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 512; i += 64 * WAVES) lut[i >> 8][i & 255] = make_entry<TX>(i & 255);
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__
                 if (lane == 0) part[wave][r * CH + c] = s;
             } else {
                 if (lane == 0 && r < m && ch < n)
-                    y[(int64_t)r * ld_y + ch] = from_float<TY>(epilogue_rt(s, scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl));
+                    y[(int64_t)r * ld_y + ch] = from_float<TY>(epilogue_rt(s, scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl, ch, act_begin));
             }
         }
     }
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) s += part[w][threadIdx.x];
             if (r < m && ch < n)
-                y[(int64_t)r * ld_y + ch] = from_float<TY>(epilogue_rt(s, scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl));
+                y[(int64_t)r * ld_y + ch] = from_float<TY>(epilogue_rt(s, scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl, ch, act_begin));
         }
     }
 }
@@ -198,44 +198,44 @@ bool gemv_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld
 
 template <typename TX, typename TY, int CH, int WAVES, bool KSPLIT>
 static void launch_gemv_rows(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
-                             const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
+                             const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, hipStream_t st) {
     const dim3 grid((unsigned)ceil_div(n, KSPLIT ? CH : CH * WAVES)), block(64 * WAVES);
     if (m == 1)
-        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 1, WAVES, KSPLIT>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
+        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 1, WAVES, KSPLIT>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y);
     else if (m == 2)
-        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 2, WAVES, KSPLIT>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
+        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 2, WAVES, KSPLIT>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y);
     else
-        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 4, WAVES, KSPLIT>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, y, ld_y);
+        hipLaunchKernelGGL((gemv_kernel<TX, TY, CH, 4, WAVES, KSPLIT>), grid, block, 0, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y);
 }
 
 template <typename TX, typename TY>
 static int launch_gemv_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
-                          const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
+                          const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, hipStream_t st) {
     // few channels: 2 per wave so that the layer still makes >= 2 waves per SIMD; many channels: 8 per wave (activations
     // reused), and with a long k the block's 4 waves split it (4x the waves and the bytes in flight)
-    if (n < 16384) launch_gemv_rows<TX, TY, 2, 4, false>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
-    else if (k >= 8192) launch_gemv_rows<TX, TY, 8, 4, true>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
-    else launch_gemv_rows<TX, TY, 8, 1, false>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, ld_y, st);
+    if (n < 16384) launch_gemv_rows<TX, TY, 2, 4, false>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, st);
+    else if (k >= 8192) launch_gemv_rows<TX, TY, 8, 4, true>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, st);
+    else launch_gemv_rows<TX, TY, 8, 1, false>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, st);
     TVL_LAUNCH_CHECK();
     return TVL_OK;
 }
 
 template <typename TX>
 static int launch_gemv_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
-                         const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
+                         const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
     switch (y_dtype) {
-        case TVL_F32: return launch_gemv_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (float*)y, ld_y, st);
-        case TVL_F16: return launch_gemv_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (f16*)y, ld_y, st);
-        case TVL_BF16: return launch_gemv_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, (bf16_t*)y, ld_y, st);
+        case TVL_F32: return launch_gemv_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (float*)y, ld_y, st);
+        case TVL_F16: return launch_gemv_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (f16*)y, ld_y, st);
+        case TVL_BF16: return launch_gemv_xy(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, (bf16_t*)y, ld_y, st);
         default: set_error("ternary_matmul: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
     }
 }
 
 int launch_gemv(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
-                const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
-    if (x_dtype == TVL_F16) return launch_gemv_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
-    if (x_dtype == TVL_BF16) return launch_gemv_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
-    return launch_gemv_x((const float*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
+                const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
+    if (x_dtype == TVL_F16) return launch_gemv_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+    if (x_dtype == TVL_BF16) return launch_gemv_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+    return launch_gemv_x((const float*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
 }
 
 }  // namespace tvl

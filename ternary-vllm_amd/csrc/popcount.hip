@@ -83,7 +83,7 @@ template <typename TY, int ROWS>
 __global__ void __launch_bounds__(256) popcount_rows_kernel(const uint32_t* __restrict__ xb, int m, int64_t ld_xb,
                                                             const uint32_t* __restrict__ pos, const uint32_t* __restrict__ neg, int64_t n,
                                                             int64_t ld_planes, int words, const float* __restrict__ scale,
-                                                            const float* __restrict__ bias, float clip, int act, TY* __restrict__ y, int64_t ld_y) {
+                                                            const float* __restrict__ bias, float clip, int act, int act_begin, TY* __restrict__ y, int64_t ld_y) {
     const int lane = threadIdx.x & 63;
     const int64_t ch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // wave-uniform
     if (ch >= n) return;
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) popcount_rows_kernel(const uint32_t* __re
         if (r < m) {
             const int dot = 2 * wave_sum(p[r] - q[r]) - c;
             if (lane == 0)
-                y[(int64_t)r * ld_y + ch] = from_float<TY>(epilogue_rt((float)dot, scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl));
+                y[(int64_t)r * ld_y + ch] = from_float<TY>(epilogue_rt((float)dot, scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl, (int)ch, act_begin));
         }
     }
 }
@@ -121,7 +121,7 @@ template <typename TY>
 __global__ void __launch_bounds__(256) popcount_tile_kernel(const uint32_t* __restrict__ xb, int64_t m, int64_t ld_xb,
                                                             const uint32_t* __restrict__ pos, const uint32_t* __restrict__ neg, int64_t n,
                                                             int64_t ld_planes, int words, const float* __restrict__ scale,
-                                                            const float* __restrict__ bias, float clip, int act, TY* __restrict__ y, int64_t ld_y) {
+                                                            const float* __restrict__ bias, float clip, int act, int act_begin, TY* __restrict__ y, int64_t ld_y) {
     constexpr int WC = 32;                      // words per k chunk (1024 elements)
     __shared__ uint32_t sx[64][WC + 1], sp[64][WC + 1], sn[64][WC + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) popcount_tile_kernel(const uint32_t* __re
         for (int j = 0; j < 4; ++j) {
             const int64_t ch = n0 + tx * 4 + j;
             if (ch < n)
-                y[row * ld_y + ch] = from_float<TY>(epilogue_rt((float)(2 * acc[i][j] - cnt[j]), scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl));
+                y[row * ld_y + ch] = from_float<TY>(epilogue_rt((float)(2 * acc[i][j] - cnt[j]), scale[ch], has_bias ? bias[ch] : 0.0f, has_bias, act, cl, (int)ch, act_begin));
         }
     }
 }
@@ -195,26 +195,26 @@ int launch_bitplanes(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, uin
 
 template <typename TY>
 static int launch_popcount_t(const uint32_t* xb, int64_t m, int64_t ld_xb, const uint32_t* pos, const uint32_t* neg, int64_t n, int64_t ld_planes,
-                             int64_t k, const float* scale, const float* bias, float clip, int act, TY* y, int64_t ld_y, hipStream_t st) {
+                             int64_t k, const float* scale, const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, hipStream_t st) {
     const int words = (int)ceil_div(k, 32);
     if (m <= 8) {
         const dim3 grid((unsigned)ceil_div(n, 4)), block(256);
-        if (m <= 2) hipLaunchKernelGGL((popcount_rows_kernel<TY, 2>), grid, block, 0, st, xb, (int)m, ld_xb, pos, neg, n, ld_planes, words, scale, bias, clip, act, y, ld_y);
-        else hipLaunchKernelGGL((popcount_rows_kernel<TY, 8>), grid, block, 0, st, xb, (int)m, ld_xb, pos, neg, n, ld_planes, words, scale, bias, clip, act, y, ld_y);
+        if (m <= 2) hipLaunchKernelGGL((popcount_rows_kernel<TY, 2>), grid, block, 0, st, xb, (int)m, ld_xb, pos, neg, n, ld_planes, words, scale, bias, clip, act, act_begin, y, ld_y);
+        else hipLaunchKernelGGL((popcount_rows_kernel<TY, 8>), grid, block, 0, st, xb, (int)m, ld_xb, pos, neg, n, ld_planes, words, scale, bias, clip, act, act_begin, y, ld_y);
     } else {
         const dim3 grid((unsigned)ceil_div(n, 64), (unsigned)ceil_div(m, 64)), block(256);
-        hipLaunchKernelGGL((popcount_tile_kernel<TY>), grid, block, 0, st, xb, m, ld_xb, pos, neg, n, ld_planes, words, scale, bias, clip, act, y, ld_y);
+        hipLaunchKernelGGL((popcount_tile_kernel<TY>), grid, block, 0, st, xb, m, ld_xb, pos, neg, n, ld_planes, words, scale, bias, clip, act, act_begin, y, ld_y);
     }
     TVL_LAUNCH_CHECK();
     return TVL_OK;
 }
 
 int launch_popcount_matmul(const uint32_t* xb, int64_t m, int64_t ld_xb, const uint32_t* pos, const uint32_t* neg, int64_t n, int64_t ld_planes,
-                           int64_t k, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
+                           int64_t k, const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
     switch (y_dtype) {
-        case TVL_F32: return launch_popcount_t(xb, m, ld_xb, pos, neg, n, ld_planes, k, scale, bias, clip, act, (float*)y, ld_y, st);
-        case TVL_F16: return launch_popcount_t(xb, m, ld_xb, pos, neg, n, ld_planes, k, scale, bias, clip, act, (f16*)y, ld_y, st);
-        case TVL_BF16: return launch_popcount_t(xb, m, ld_xb, pos, neg, n, ld_planes, k, scale, bias, clip, act, (bf16_t*)y, ld_y, st);
+        case TVL_F32: return launch_popcount_t(xb, m, ld_xb, pos, neg, n, ld_planes, k, scale, bias, clip, act, act_begin, (float*)y, ld_y, st);
+        case TVL_F16: return launch_popcount_t(xb, m, ld_xb, pos, neg, n, ld_planes, k, scale, bias, clip, act, act_begin, (f16*)y, ld_y, st);
+        case TVL_BF16: return launch_popcount_t(xb, m, ld_xb, pos, neg, n, ld_planes, k, scale, bias, clip, act, act_begin, (bf16_t*)y, ld_y, st);
         default: set_error("popcount_matmul: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
     }
 }

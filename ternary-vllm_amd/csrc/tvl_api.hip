@@ -118,6 +118,18 @@ size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k) {
 int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
                        const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y,
                        void* workspace, size_t workspace_bytes, void* stream) {
+    return tvl_ternary_matmul_act_from(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, 0, y, y_dtype, ld_y, workspace,
+                                       workspace_bytes, stream);
+}
+
+int tvl_ternary_matmul_act_from(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
+                                int64_t ld_pw, const float* scale, const float* bias, float clip, int act, int64_t act_begin_channel,
+                                void* y, int y_dtype, int64_t ld_y, void* workspace, size_t workspace_bytes, void* stream) {
+    TVL_REQUIRE(act_begin_channel >= 0 && act_begin_channel <= (n > 0 ? n : 0), "ternary_matmul: act_begin_channel=%lld outside [0, n=%lld]",
+                (long long)act_begin_channel, (long long)n);
+    TVL_REQUIRE(n <= INT32_MAX, "ternary_matmul: n=%lld too large", (long long)n);
+    if (act_begin_channel >= n) act = act == TVL_ACT_GELU_TANH ? TVL_ACT_NONE : act;   // no channel carries the activation
+    const int act_begin = act == TVL_ACT_NONE ? 0 : (int)act_begin_channel;
     TVL_REQUIRE(m >= 0 && n >= 0 && k >= 0, "ternary_matmul: negative shape m=%lld n=%lld k=%lld", (long long)m, (long long)n, (long long)k);
     TVL_REQUIRE(float_dtype(x_dtype), "ternary_matmul: activation dtype must be f32/f16/bf16, got %d", x_dtype);
     TVL_REQUIRE(float_dtype(y_dtype), "ternary_matmul: output dtype must be f32/f16/bf16, got %d", y_dtype);
@@ -138,14 +150,14 @@ int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t
                 "ternary_matmul: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     if (gemv_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
-        return launch_gemv(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
+        return launch_gemv(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
     if (gemm_stream_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
-        return launch_gemm_stream(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
+        return launch_gemm_stream(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     if (gemm_skinny_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
-        return launch_gemm_skinny(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
+        return launch_gemm_skinny(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     if (gemm_mfma_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
-        return launch_gemm_mfma(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, workspace, workspace_bytes, st);
-    return launch_gemm_generic(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, y, y_dtype, ld_y, st);
+        return launch_gemm_mfma(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
+    return launch_gemm_generic(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
 }
 
 int tvl_sign_pack_bits(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, uint32_t* xb, int64_t ld_xb, void* stream) {
@@ -188,7 +200,7 @@ int tvl_popcount_matmul(const uint32_t* xb, int64_t m, int64_t ld_xb, const uint
     TVL_REQUIRE(k == 0 || (xb && pos && neg), "popcount_matmul: NULL input pointer");
     TVL_REQUIRE(aligned(xb, 4) && aligned(pos, 4) && aligned(neg, 4) && aligned(y, dtype_size(y_dtype)) && aligned(scale, 4) && aligned(bias, 4),
                 "popcount_matmul: misaligned pointer");
-    return launch_popcount_matmul(xb, m, ld_xb, pos, neg, n, ld_planes, k, scale, bias, clip, act, y, y_dtype, ld_y, (hipStream_t)stream);
+    return launch_popcount_matmul(xb, m, ld_xb, pos, neg, n, ld_planes, k, scale, bias, clip, act, 0, y, y_dtype, ld_y, (hipStream_t)stream);
 }
 
 int tvl_ternary_mm_f32(const float* x, int64_t m, int64_t k, int64_t ld_x, const float* tm, int64_t n, int64_t ld_tm, float* res,

@@ -102,10 +102,22 @@ __device__ __forceinline__ float epilogue(float acc, float scale, float bias, fl
     return y;
 }
 
+// the activation only on channels >= act_begin: a layer whose leading channels are linear and whose trailing channels
+// carry the activation (two Dense layers that share their input, run as one product)
+template <bool HAS_BIAS, int ACT>
+__device__ __forceinline__ float epilogue_ch(float acc, float scale, float bias, float clip, int ch, int act_begin) {
+    float y = epilogue<HAS_BIAS, TVL_ACT_NONE>(acc, scale, bias, clip);
+    if constexpr (ACT == TVL_ACT_GELU_TANH) {
+        if (ch >= act_begin) y = gelu_tanh_f32(y);
+    }
+    return y;
+}
+
 // the same with the bias / activation choice made at run time (kernels where the epilogue is a vanishing share)
-__device__ __forceinline__ float epilogue_rt(float acc, float scale, float bias, bool has_bias, int act, float clip) {
-    if (has_bias) return act == TVL_ACT_GELU_TANH ? epilogue<true, TVL_ACT_GELU_TANH>(acc, scale, bias, clip) : epilogue<true, TVL_ACT_NONE>(acc, scale, bias, clip);
-    return act == TVL_ACT_GELU_TANH ? epilogue<false, TVL_ACT_GELU_TANH>(acc, scale, bias, clip) : epilogue<false, TVL_ACT_NONE>(acc, scale, bias, clip);
+__device__ __forceinline__ float epilogue_rt(float acc, float scale, float bias, bool has_bias, int act, float clip, int ch = 0, int act_begin = 0) {
+    const bool gelu = act == TVL_ACT_GELU_TANH && ch >= act_begin;
+    if (has_bias) return gelu ? epilogue<true, TVL_ACT_GELU_TANH>(acc, scale, bias, clip) : epilogue<true, TVL_ACT_NONE>(acc, scale, bias, clip);
+    return gelu ? epilogue<false, TVL_ACT_GELU_TANH>(acc, scale, bias, clip) : epilogue<false, TVL_ACT_NONE>(acc, scale, bias, clip);
 }
 
 }  // namespace tvl

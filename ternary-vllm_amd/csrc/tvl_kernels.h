@@ -20,7 +20,7 @@ int launch_copy_u8(const uint8_t* in, int64_t numel, uint8_t* out, hipStream_t s
 
 // gemm_generic.hip
 int launch_gemm_generic(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
-                        int64_t ld_pw, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype,
+                        int64_t ld_pw, const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype,
                         int64_t ld_y, hipStream_t st);
 int launch_ternary_mm(const float* x, int64_t m, int64_t k, int64_t ld_x, const float* tm, int64_t n, int64_t ld_tm, float* res,
                       int64_t ld_res, hipStream_t st);
@@ -29,16 +29,16 @@ int launch_ternary_mm(const float* x, int64_t m, int64_t k, int64_t ld_x, const 
 bool gemm_mfma_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
                          int64_t ld_pw, const void* workspace, size_t workspace_bytes);
 int launch_gemm_mfma(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
-                     int64_t ld_pw, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype,
+                     int64_t ld_pw, const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype,
                      int64_t ld_y, void* workspace, size_t workspace_bytes, hipStream_t st);
 size_t gemm_mfma_workspace_bytes(int x_dtype, int64_t m, int64_t n, int64_t k);
 int launch_splitk_reduce(const float* slab, int splits, int64_t m, int64_t n, const float* scale, const float* bias, float clip,
-                         int act, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
+                         int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
 
 // gemm_skinny.hip
 bool gemm_skinny_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw);
 int launch_gemm_skinny(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                       const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, void* workspace,
+                       const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, void* workspace,
                        size_t workspace_bytes, hipStream_t st);
 size_t gemm_skinny_workspace_bytes(int64_t m, int64_t n, int64_t k);
 
@@ -46,20 +46,20 @@ size_t gemm_skinny_workspace_bytes(int64_t m, int64_t n, int64_t k);
 bool gemm_stream_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
                            const void* workspace, size_t workspace_bytes);
 int launch_gemm_stream(const void* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                       const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, void* workspace,
+                       const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, void* workspace,
                        size_t workspace_bytes, hipStream_t st);
 size_t gemm_stream_workspace_bytes(int64_t m, int64_t n, int64_t k);
 
 // gemv.hip
 bool gemv_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw);
 int launch_gemv(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
-                const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
+                const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
 
 // popcount.hip
 int launch_sign_bits(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, uint32_t* xb, int64_t ld_xb, hipStream_t st);
 int launch_bitplanes(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, uint32_t* pos, uint32_t* neg, int64_t ld_planes, hipStream_t st);
 int launch_popcount_matmul(const uint32_t* xb, int64_t m, int64_t ld_xb, const uint32_t* pos, const uint32_t* neg, int64_t n, int64_t ld_planes,
-                           int64_t k, const float* scale, const float* bias, float clip, int act, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
+                           int64_t k, const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
 
 // fit_scale.hip
 size_t fit_workspace_bytes();

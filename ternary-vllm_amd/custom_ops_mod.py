@@ -46,6 +46,8 @@ SIGNATURES = {
     "tvl_quantize": (_c_int, [_c_vp, _c_int, _c_i64, _c_int, _c_f32, _c_vp, _c_int, _c_vp]),
     "tvl_ternary_matmul": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_f32,
                                     _c_int, _c_vp, _c_int, _c_i64, _c_vp, _c_sz, _c_vp]),
+    "tvl_ternary_matmul_act_from": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_f32,
+                                             _c_int, _c_i64, _c_vp, _c_int, _c_i64, _c_vp, _c_sz, _c_vp]),
     "tvl_ternary_matmul_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tvl_ternary_matmul_workspace_bytes_for": (_c_sz, [_c_int, _c_i64, _c_i64, _c_i64]),
     "tvl_sign_pack_bits": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_vp]),
@@ -320,13 +322,15 @@ def _matmul_workspace(device: torch.device, stream: int, x_dtype: int, m: int, n
 
 def ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias: Optional[torch.Tensor], clip_val: float,
                    activation: Optional[str] = None, out_dtype: Optional[torch.dtype] = None,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, act_begin: int = 0) -> torch.Tensor:
     """``act(clip((x @ unpack(pw)^T) * scale + bias, +-clip_val))``.
 
     ``ops.ternary_matmul(x, pw, scale, bias, clip)`` at ``impl/tf/moondream/ternary.py:281``; the
     order of operations is ``binary/modules.py:104-108``.  ``x``: ``[..., K]`` f16 / bf16 / f32;
     ``pw``: uint8 ``[N, >= ceil(K/4)]``; ``scale``, ``bias``: ``[N]``.  The optional activation
     (the reference applies it after the op, ``ternary.py:298-299``) is fused into the kernel.
+    ``act_begin``: output channels below it get no activation - two Dense layers on one input (the Phi
+    block's Wqkv and fc1, ``impl/tf/moondream/layers.py:334-347``) stored as one packed matrix, one launch.
     """
     x = _gpu(x, "ternary_matmul(x)")
     if activation not in _ACTS:
@@ -349,14 +353,17 @@ def ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias:
         if y.shape[0] != m or y.data_ptr() != out.data_ptr():
             raise ValueError("ternary_matmul: `out` must be a contiguous [..., N] tensor matching x")
     xdt = _dt(x2, "ternary_matmul(x)")
+    act_begin = int(act_begin)
+    if act_begin < 0 or act_begin > n:
+        raise ValueError(f"ternary_matmul: act_begin={act_begin} outside [0, {n}]")
 
     def launch():
         stream = _stream(x)
         ws_ptr, ws_bytes = _matmul_workspace(x.device, stream, xdt, m, n, k)
-        _check(_lib.tvl_ternary_matmul(x2.data_ptr(), xdt, m, k, _ld(x2), pw.data_ptr(), n, _ld(pw),
-                                       scale.data_ptr(), bias.data_ptr() if bias is not None else None, float(clip_val),
-                                       _ACTS[activation], y.data_ptr(), _dt(y, "ternary_matmul(out)"), _ld(y), ws_ptr, ws_bytes,
-                                       stream))
+        _check(_lib.tvl_ternary_matmul_act_from(x2.data_ptr(), xdt, m, k, _ld(x2), pw.data_ptr(), n, _ld(pw),
+                                                scale.data_ptr(), bias.data_ptr() if bias is not None else None, float(clip_val),
+                                                _ACTS[activation], act_begin, y.data_ptr(), _dt(y, "ternary_matmul(out)"), _ld(y),
+                                                ws_ptr, ws_bytes, stream))
 
     if torch.cuda.current_device() == x.device.index:   # skip the device guard (several microseconds) when it is a no-op
         launch()
@@ -375,8 +382,9 @@ class PreparedMatmul:
     can be captured in a HIP graph does not need it."""
 
     def __init__(self, x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias: Optional[torch.Tensor], clip_val: float,
-                 activation: Optional[str] = None, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None):
-        self.out = ternary_matmul(x, pw, scale, bias, clip_val, activation, out_dtype, out)   # validates, allocates, runs once
+                 activation: Optional[str] = None, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None,
+                 act_begin: int = 0):
+        self.out = ternary_matmul(x, pw, scale, bias, clip_val, activation, out_dtype, out, act_begin)   # validates, allocates, runs once
         k, n = x.shape[-1], pw.shape[0]
         x2 = x.reshape(-1, k)
         if x2.data_ptr() != x.data_ptr() or (x2.shape[0] > 1 and x2.stride(0) < k) or (k > 1 and x2.stride(1) != 1):
@@ -389,12 +397,12 @@ class PreparedMatmul:
         self._shape = (_dt(x2, "x"), x2.shape[0], n, k)
         self._args_head = (x2.data_ptr(), _dt(x2, "x"), x2.shape[0], k, _ld(x2), pw.data_ptr(), n, _ld(pw), self._scale.data_ptr(),
                            self._bias.data_ptr() if self._bias is not None else None, float(clip_val), _ACTS[activation],
-                           y2.data_ptr(), _dt(y2, "out"), _ld(y2))
+                           int(act_begin), y2.data_ptr(), _dt(y2, "out"), _ld(y2))
 
     def __call__(self) -> torch.Tensor:
         stream = int(torch.cuda.current_stream(self._device).cuda_stream)
         ws_ptr, ws_bytes = _matmul_workspace(self._device, stream, *self._shape)
-        _check(_lib.tvl_ternary_matmul(*self._args_head, ws_ptr, ws_bytes, stream))
+        _check(_lib.tvl_ternary_matmul_act_from(*self._args_head, ws_ptr, ws_bytes, stream))
         return self.out
 
 

@@ -7,7 +7,9 @@ rebuilds the part of that loop the packed path lives in, from the model's publis
 (``impl/tf/moondream/layers.py:385-405``: hidden 2048, 32 heads, intermediate 8192, 24 blocks, partial rotary
 0.5, layer-norm eps 1e-5) and block structure (``layers.py:334-347``: one LayerNorm feeding both attention and
 MLP, ``out = attn + mlp + residual``): per block four packed matmuls - Wqkv, out_proj, fc1 (+ tanh-GELU in the
-matmul epilogue, ``utils/conversion.py:185-187``) and fc2 - with random ternary weights.
+matmul epilogue, ``utils/conversion.py:185-187``) and fc2 - with random ternary weights.  Wqkv and fc1 read the
+same LayerNorm output, so by default they run as ONE packed matmul over 6144 + 8192 channels whose activation
+starts at channel 6144 (``DecoderConfig.fuse_qkv_fc1``): three launches per block instead of four.
 
 A decode step has ~100 short kernels; launched one by one it is bound by the host.  The step is therefore
 captured once into a HIP graph (static cache buffers, position kept on the device) and replayed.
@@ -35,6 +37,7 @@ class DecoderConfig:
     eps: float = 1e-5
     clip: float = 100.0
     max_len: int = 1024
+    fuse_qkv_fc1: bool = True     # Wqkv | fc1 as one packed matrix, tanh-GELU from channel 3 * hidden on
 
     @property
     def head_dim(self) -> int:
@@ -57,11 +60,26 @@ class PackedLinear:
         self.scale = (torch.rand(out_features, generator=gen) * 0.5 + 0.75).mul_(1.0 / math.sqrt(in_features * 2.0 / 3.0)).to(device)
         self.bias = (torch.randn(out_features, generator=gen) * 0.02).to(device)
         self.activation = activation
+        self.act_begin = 0                                 # first output channel that gets the activation
         self.clip = clip
         self.out_features, self.in_features = out_features, in_features
 
+    @classmethod
+    def stacked(cls, linear: "PackedLinear", activated: "PackedLinear") -> "PackedLinear":
+        """Two layers on the same input as one: rows, scales and biases concatenated, ``activated``'s activation
+        applied from its first channel on."""
+        assert linear.in_features == activated.in_features and linear.activation is None and linear.clip == activated.clip
+        f = cls.__new__(cls)
+        f.ternary = torch.cat([linear.ternary, activated.ternary])
+        f.pw = torch.cat([linear.pw, activated.pw]).contiguous()
+        f.scale = torch.cat([linear.scale, activated.scale]).contiguous()
+        f.bias = torch.cat([linear.bias, activated.bias]).contiguous()
+        f.activation, f.act_begin, f.clip = activated.activation, linear.out_features, linear.clip
+        f.out_features, f.in_features = linear.out_features + activated.out_features, linear.in_features
+        return f
+
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.ternary_matmul(x, self.pw, self.scale, self.bias, self.clip, activation=self.activation)
+        return ops.ternary_matmul(x, self.pw, self.scale, self.bias, self.clip, activation=self.activation, act_begin=self.act_begin)
 
     def reference(self, x: torch.Tensor) -> torch.Tensor:
         """The same layer with dense float32 weights in plain torch (``binary/modules.py:101-109`` order)."""
@@ -70,7 +88,7 @@ class PackedLinear:
         y = y * self.scale + self.bias
         y = y.clip(-self.clip, self.clip)
         if self.activation == "gelu_tanh":
-            y = torch.nn.functional.gelu(y, approximate="tanh")
+            y = torch.cat([y[..., :self.act_begin], torch.nn.functional.gelu(y[..., self.act_begin:], approximate="tanh")], dim=-1)
         return y
 
     @property
@@ -88,8 +106,11 @@ class Block:
         self.out_proj = PackedLinear(h, h, gen, device, clip=cfg.clip)
         self.fc1 = PackedLinear(cfg.intermediate, h, gen, device, activation="gelu_tanh", clip=cfg.clip)
         self.fc2 = PackedLinear(h, cfg.intermediate, gen, device, clip=cfg.clip)
+        self.qkv_fc1 = PackedLinear.stacked(self.wqkv, self.fc1) if cfg.fuse_qkv_fc1 else None
 
     def linears(self) -> List[PackedLinear]:
+        if self.qkv_fc1 is not None:
+            return [self.qkv_fc1, self.out_proj, self.fc2]
         return [self.wqkv, self.out_proj, self.fc1, self.fc2]
 
 
@@ -129,7 +150,11 @@ class TernaryDecoderStack:
         cfg = self.cfg
         b, t, _ = h.shape
         x = torch.nn.functional.layer_norm(h, (cfg.hidden,), blk.ln_w.to(h.dtype), blk.ln_b.to(h.dtype), cfg.eps)
-        qkv = self.linear(blk.wqkv, x).to(h.dtype).view(b, t, 3, cfg.heads, cfg.head_dim)
+        if blk.qkv_fc1 is not None:
+            z = self.linear(blk.qkv_fc1, x).to(h.dtype)
+            qkv, fc1_out = z[..., : 3 * cfg.hidden].reshape(b, t, 3, cfg.heads, cfg.head_dim), z[..., 3 * cfg.hidden:]
+        else:
+            qkv, fc1_out = self.linear(blk.wqkv, x).to(h.dtype).view(b, t, 3, cfg.heads, cfg.head_dim), None
         q, k, v = (qkv[:, :, j].transpose(1, 2) for j in range(3))            # [b, heads, t, hd]
         rd = cfg.rotary_dim
         cos, sin = self.cos[positions].to(h.dtype), self.sin[positions].to(h.dtype)   # [t, rd]
@@ -141,7 +166,9 @@ class TernaryDecoderStack:
         att = torch.nn.functional.scaled_dot_product_attention(q, kc.to(h.dtype), vc.to(h.dtype), attn_mask=mask)
         att = att.transpose(1, 2).reshape(b, t, cfg.hidden)
         attn_out = self.linear(blk.out_proj, att).to(h.dtype)
-        mlp = self.linear(blk.fc2, self.linear(blk.fc1, x).to(h.dtype)).to(h.dtype)
+        if fc1_out is None:
+            fc1_out = self.linear(blk.fc1, x).to(h.dtype)
+        mlp = self.linear(blk.fc2, fc1_out).to(h.dtype)
         return attn_out + mlp + h
 
     def _forward(self, h: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:

@@ -229,15 +229,18 @@ def test_to_packed_inference_and_arena(tv, dev, tmp_path):
 
 def test_decode_harness_matches_dense_reference_and_graph_replay(dev):
     """Packed matmuls inside a (small) Phi-style decoder: prefill + steps against the same stack with dense float32
-    torch layers; the graph-captured step reproduces the eager step bit for bit."""
+    torch layers; the graph-captured step reproduces the eager step bit for bit; Wqkv | fc1 as one matmul (the
+    default) gives the same bits as the two separate matmuls."""
     from ternary_vllm_amd import decode_harness as dh
     cfg = dh.DecoderConfig(hidden=256, heads=4, intermediate=1024, blocks=2, max_len=64)
+    cfg_unfused = dh.DecoderConfig(hidden=256, heads=4, intermediate=1024, blocks=2, max_len=64, fuse_qkv_fc1=False)
     torch.manual_seed(3)
     prompt = torch.randn(2, 19, cfg.hidden, device=dev)
     toks = [torch.randn(2, 1, cfg.hidden, device=dev) for _ in range(4)]
 
-    def run(reference, graph):
+    def run(reference, graph, cfg=cfg):
         st = dh.TernaryDecoderStack(cfg, batch=2, device=dev, dtype=torch.float32, seed=11)
+        assert len(st.blocks[0].linears()) == (3 if cfg.fuse_qkv_fc1 else 4)
         if reference:
             st.linear = lambda layer, x: layer.reference(x)
         outs = [st.prefill(prompt)]
@@ -253,6 +256,8 @@ def test_decode_harness_matches_dense_reference_and_graph_replay(dev):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
     for a, b in zip(packed, replay):
+        assert torch.equal(a, b)
+    for a, b in zip(packed, run(False, False, cfg_unfused)):
         assert torch.equal(a, b)
 
 

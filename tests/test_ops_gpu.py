@@ -361,6 +361,41 @@ def test_matmul_gelu_epilogue(ops, dev):
         assert np.max(np.abs(got.cpu().numpy() - want)) <= 1e-5  # float32 tanh vs float64 oracle
 
 
+@pytest.mark.parametrize("m,n,k,xdt", [
+    (1, 192, 256, torch.float16),       # one-launch few-row kernel
+    (3, 160, 128, torch.float32),       # the same with float32 activations
+    (8, 384, 512, torch.float16),       # weight-stream kernel
+    (12, 20480, 2048, torch.float16),   # weight-stream kernel with split-K + reduce
+    (24, 256, 512, torch.bfloat16),     # skinny matrix-core kernel
+    (300, 384, 256, torch.float16),     # small matrix-core tiles / split-K
+    (1024, 1024, 256, torch.float16),   # 256 x 256 tile
+    (520, 4608, 128, torch.bfloat16),   # persistent 256 x 256 tile loop
+    (300, 384, 256, torch.float32),     # float32 activations on the matrix cores
+    (21, 50, 38, torch.float16),        # generic kernel
+])
+def test_matmul_activation_from_channel(ops, dev, m, n, k, xdt):
+    """Two layers on one input stored as one packed matrix (Wqkv | fc1 of the Phi block, layers.py:334-347): channels
+    below act_begin stay linear, the rest get tanh-GELU.  Bit-identical to the two separate calls, and equal to the
+    oracle; act_begin placed off every tile boundary."""
+    rng = np.random.default_rng(77)
+    x, pw, scale, b = _case(rng, m, n, k)
+    scale *= 0.1
+    a0 = n // 3 + 5
+    xt = torch.from_numpy(x).to(dev).to(xdt)
+    pwt, st, bt = torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev), torch.from_numpy(b).to(dev)
+    got = ops.ternary_matmul(xt, pwt, st, bt, 100.0, activation="gelu_tanh", out_dtype=torch.float32, act_begin=a0)
+    want = O.ternary_matmul(xt.float().cpu().numpy(), pw, scale, b, 100.0, act=O.ACT_GELU_TANH, act_begin=a0)
+    assert np.max(np.abs(got.cpu().numpy() - want)) <= 1e-5
+    lin = ops.ternary_matmul(xt, pwt, st, bt, 100.0, out_dtype=torch.float32)
+    act = ops.ternary_matmul(xt, pwt, st, bt, 100.0, activation="gelu_tanh", out_dtype=torch.float32)
+    assert torch.equal(got[:, :a0], lin[:, :a0]) and torch.equal(got[:, a0:], act[:, a0:])
+    # act_begin == n: no channel carries the activation; == 0: all do
+    assert torch.equal(ops.ternary_matmul(xt, pwt, st, bt, 100.0, activation="gelu_tanh", out_dtype=torch.float32, act_begin=n), lin)
+    assert torch.equal(ops.ternary_matmul(xt, pwt, st, bt, 100.0, activation="gelu_tanh", out_dtype=torch.float32, act_begin=0), act)
+    with pytest.raises(ValueError):
+        ops.ternary_matmul(xt, pwt, st, bt, 100.0, activation="gelu_tanh", act_begin=n + 1)
+
+
 def test_matmul_matches_reference_forward_golden(ops, dev, golden_dir):
     """Golden outputs of the reference's ScaledTernaryLinear / ScaledBinary*Linear forward."""
     g = np.load(os.path.join(golden_dir, "scaled_linear_forward.npz"))
