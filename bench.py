@@ -253,43 +253,44 @@ def main():
                "gemm_frac_of_hbm_peak": round(by / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "note": "4096^3 with f16 activations is matrix-core bound (1927 op/B): its HBM fraction is capped near 16 %"}
 
-        # ---- HBM-bound kernel of the path: quantize + pack (f32 in, 2 bits out), cache-cold buffers
-        nw = 6  # 6 x 64 MiB of latent weights > 256 MiB Infinity Cache
-        wl = [torch.rand(N, K, device=dev) * 2 - 1 for _ in range(nw)]
-        pws = [torch.empty_like(pw) for _ in range(nw)]
-        p_avg, p_best = time_launches(lambda i: ops.ternarize_pack(wl[i % nw], 0.5, out=pws[i % nw]), 2 * nw, nw)
-        pack_bytes = N * K * 4 + N * ((K + 3) // 4)
-        hbm["pack_kernel"] = {"kernel": "tvl::quantize_pack_fast_kernel<float, ternary>", "shape": [N, K],
-                              "algorithmic_bytes": pack_bytes, "avg_launch_ms": round(p_avg, 4),
-                              "GBps": round(pack_bytes / (p_avg * 1e-3) / 1e9, 1),
-                              "frac_of_hbm_peak": round(pack_bytes / (p_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        del wl, pws
-        # ---- HBM-bound form of the matmul: one activation row (decode), weights streamed once from HBM.
-        # 16384 x 16384 (64 MiB packed, 10 rotating copies) is large enough to leave the launch-latency regime.
-        for (dn, dk, tag) in ((16384, 16384, "decode_m1_16384"), (N, K, "decode_m1")):
-            nd = max(2, min(40, (640 << 20) // (dn * dk // 4)))
-            pwd = [torch.randint(0, 171, (dn, dk // 4), dtype=torch.uint8, device=dev) for _ in range(nd)]
-            xd = torch.randn(1, dk, device=dev).half()
-            yd = torch.empty((1, dn), dtype=torch.float16, device=dev)
-            sd, bd = torch.ones(dn, device=dev), torch.zeros(dn, device=dev)
-            d_avg, d_best, how = time_graph(lambda i: ops.ternary_matmul(xd, pwd[i % nd], sd, bd, 100.0, out=yd), 2 * nd, nd)
-            d_bytes = gemm_bytes(1, dn, dk, 2)
-            hbm[tag] = {"kernel": "tvl::gemv_kernel (one launch: table-lookup decode + v_dot2c, wave-level DPP reduction)", "shape": [1, dn, dk], "timing": how,
-                        "algorithmic_bytes": d_bytes, "avg_call_ms": round(d_avg, 5), "GBps": round(d_bytes / (d_avg * 1e-3) / 1e9, 1),
-                        "frac_of_hbm_peak": round(d_bytes / (d_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            del pwd
+        if world == 1:   # the side measurements are single-GPU figures; multi-GPU runs report the sharded GEMM only
+            # ---- HBM-bound kernel of the path: quantize + pack (f32 in, 2 bits out), cache-cold buffers
+            nw = 6  # 6 x 64 MiB of latent weights > 256 MiB Infinity Cache
+            wl = [torch.rand(N, K, device=dev) * 2 - 1 for _ in range(nw)]
+            pws = [torch.empty_like(pw) for _ in range(nw)]
+            p_avg, p_best = time_launches(lambda i: ops.ternarize_pack(wl[i % nw], 0.5, out=pws[i % nw]), 2 * nw, nw)
+            pack_bytes = N * K * 4 + N * ((K + 3) // 4)
+            hbm["pack_kernel"] = {"kernel": "tvl::quantize_pack_fast_kernel<float, ternary>", "shape": [N, K],
+                                  "algorithmic_bytes": pack_bytes, "avg_launch_ms": round(p_avg, 4),
+                                  "GBps": round(pack_bytes / (p_avg * 1e-3) / 1e9, 1),
+                                  "frac_of_hbm_peak": round(pack_bytes / (p_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del wl, pws
+            # ---- HBM-bound form of the matmul: one activation row (decode), weights streamed once from HBM.
+            # 16384 x 16384 (64 MiB packed, 10 rotating copies) is large enough to leave the launch-latency regime.
+            for (dn, dk, tag) in ((16384, 16384, "decode_m1_16384"), (N, K, "decode_m1")):
+                nd = max(2, min(40, (640 << 20) // (dn * dk // 4)))
+                pwd = [torch.randint(0, 171, (dn, dk // 4), dtype=torch.uint8, device=dev) for _ in range(nd)]
+                xd = torch.randn(1, dk, device=dev).half()
+                yd = torch.empty((1, dn), dtype=torch.float16, device=dev)
+                sd, bd = torch.ones(dn, device=dev), torch.zeros(dn, device=dev)
+                d_avg, d_best, how = time_graph(lambda i: ops.ternary_matmul(xd, pwd[i % nd], sd, bd, 100.0, out=yd), 2 * nd, nd)
+                d_bytes = gemm_bytes(1, dn, dk, 2)
+                hbm[tag] = {"kernel": "tvl::gemv_kernel (one launch: table-lookup decode + v_dot2c, wave-level DPP reduction)", "shape": [1, dn, dk], "timing": how,
+                            "algorithmic_bytes": d_bytes, "avg_call_ms": round(d_avg, 5), "GBps": round(d_bytes / (d_avg * 1e-3) / 1e9, 1),
+                            "frac_of_hbm_peak": round(d_bytes / (d_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                del pwd
 
-        # ---- the same workload with float32 activations (the reference layer's dtype): three exact bf16 planes on
-        # the matrix cores, float32 output
-        xf = torch.randn(M, K, device=dev)
-        yf = torch.empty((M, N), dtype=torch.float32, device=dev)
-        f_avg, _ = time_launches(lambda i: ops.ternary_matmul(xf, pw, scale, bias, 100.0, out=yf), 10, 3, rounds=3)
-        extra["f32_activations"] = {"shape": [M, N, K], "avg_call_ms": round(f_avg, 4),
-                                    "effective_TFLOPs": round(2.0 * M * N * K / (f_avg * 1e-3) / 1e12, 1),
-                                    "kernels": "tvl::split_f32_kernel + tvl::gemm_mfma16_kernel<bf16, f32> over 3K"}
-        del xf, yf
+            # ---- the same workload with float32 activations (the reference layer's dtype): three exact bf16 planes on
+            # the matrix cores, float32 output
+            xf = torch.randn(M, K, device=dev)
+            yf = torch.empty((M, N), dtype=torch.float32, device=dev)
+            f_avg, _ = time_launches(lambda i: ops.ternary_matmul(xf, pw, scale, bias, 100.0, out=yf), 10, 3, rounds=3)
+            extra["f32_activations"] = {"shape": [M, N, K], "avg_call_ms": round(f_avg, 4),
+                                        "effective_TFLOPs": round(2.0 * M * N * K / (f_avg * 1e-3) / 1e12, 1),
+                                        "kernels": "tvl::split_f32_kernel + tvl::gemm_mfma16_kernel<bf16, f32> over 3K"}
+            del xf, yf
 
-        if args.sweep:
+        if args.sweep and world == 1:
             sweep = []
             shapes = [(mm, 4096, 4096) for mm in (1, 16, 64, 256, 1024, 4096)]
             shapes += [(mm, nn, kk) for mm in (1, 745) for (nn, kk) in ((6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192))]

@@ -139,6 +139,39 @@ class ScaledTernaryUnpack(ScaledTernaryMatmul):
         return self._post(y, False)
 
 
+class ScaledTernaryMatmulPair(nn.Module):
+    """Two built ``ScaledTernaryMatmul`` layers that read the SAME input, run as one packed matmul: ``first`` must be
+    linear, ``second`` may carry the fusable activation (the Phi block's Wqkv and fc1 behind one LayerNorm,
+    ``impl/tf/moondream/layers.py:334-347``; fc1's GELU folded in at ``utils/conversion.py:185-187``).  The packed rows,
+    scales and biases are concatenated once; ``forward`` returns the two layers' outputs as views of one buffer."""
+
+    def __init__(self, first: ScaledTernaryMatmul, second: ScaledTernaryMatmul):
+        super().__init__()
+        if not (first.built and second.built):
+            raise RuntimeError("build() both layers (call them once) before pairing them")
+        if first.orig_shape[1] != second.orig_shape[1]:
+            raise ValueError(f"the layers read different input widths: {first.orig_shape[1]} and {second.orig_shape[1]}")
+        if first.act is not None:
+            raise ValueError("the first layer of a pair must have no activation")
+        if first.clip_val != second.clip_val:
+            raise ValueError("the layers clip at different values")
+        self.fused_act = _fusable(second.act)
+        self.post_act = None if (second.act is None or self.fused_act is not None) else second.act
+        self.k = first.orig_shape[1]
+        self.split = first.units
+        self.units = first.units + second.units
+        self.clip_val = first.clip_val
+        rb = ops.packed_row_bytes(self.k)
+        self.register_buffer("pw", torch.cat([first.pw[:, :rb], second.pw[:, :rb]]).contiguous())
+        self.register_buffer("scale", torch.cat([first.scale, second.scale]).contiguous())
+        self.register_buffer("bias", torch.cat([first.bias, second.bias]).contiguous())
+
+    def forward(self, x: torch.Tensor):
+        y = ops.ternary_matmul(x, self.pw, self.scale, self.bias, self.clip_val, activation=self.fused_act, act_begin=self.split)
+        a, b = y[..., : self.split], y[..., self.split:]
+        return a, (b if self.post_act is None else self.post_act(b))
+
+
 class ScaledTernaryTf(_PackedDenseBase):
     """``impl/tf/moondream/ternary.py:178-250``: the whole weight matrix flattened and packed in the
     planar layout B (``pack_ternary2``), unpacked on every call, dense matmul."""

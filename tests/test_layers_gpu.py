@@ -261,6 +261,28 @@ def test_decode_harness_matches_dense_reference_and_graph_replay(dev):
         assert torch.equal(a, b)
 
 
+def test_matmul_pair_equals_the_two_layers(tv, dev):
+    """Wqkv | fc1 behind one LayerNorm as one packed matmul: same bits as the two layers run separately."""
+    L = tv.layers
+    torch.manual_seed(9)
+    k = 256
+    x = torch.randn(3, 5, k, device=dev).half()
+    a, b = L.ScaledTernaryMatmul(96).to(dev), L.ScaledTernaryMatmul(160, activation="gelu_tanh").to(dev)
+    for layer in (a, b):
+        layer(x)   # build
+        n = layer.units
+        layer.set_weights([torch.rand(n) * 0.1 + 0.05, torch.randn(n) * 0.1, tv.pack_fn(torch.randint(-1, 2, (n, k), dtype=torch.int8, device=dev))])
+    pair = L.ScaledTernaryMatmulPair(a, b)
+    ya, yb = pair(x)
+    assert torch.equal(ya, a(x)) and torch.equal(yb, b(x))
+    relu = L.ScaledTernaryMatmul(160, activation=torch.relu).to(dev)     # an activation the kernel does not fuse
+    relu(x); relu.set_weights(b.get_weights())
+    ya2, yr = L.ScaledTernaryMatmulPair(a, relu)(x)
+    assert torch.equal(ya2, ya) and torch.equal(yr, relu(x))
+    with pytest.raises(ValueError):
+        L.ScaledTernaryMatmulPair(b, a)                                   # the activated layer cannot come first
+
+
 def test_prepared_matmul_matches_plain_call(dev):
     import ternary_vllm_amd as tv
     ops = tv.custom_ops_mod
