@@ -25,6 +25,7 @@ template <typename T> __device__ __forceinline__ void load4(const T* p, float (&
 // (4096^2: 14.9 -> 13.2 us; 16384 x 4096: 5.4 -> 6.1 TB/s by in-process A/B).
 typedef float nt_float4 __attribute__((ext_vector_type(4)));
 typedef uint32_t nt_uint2 __attribute__((ext_vector_type(2)));
+typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
 template <> __device__ __forceinline__ void load4<float>(const float* p, float (&o)[4]) {
     const nt_float4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_float4*>(p));
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
@@ -136,6 +137,27 @@ __global__ void __launch_bounds__(256) pack_i8_kernel(const int8_t* __restrict__
     }
 }
 
+// Fast path of pack_i8_kernel: a lane turns 16 consecutive int8 (one 16-byte load) into one dword of packed bytes.
+// Requires k % 16 == 0, 16-byte aligned int8 rows, 4-byte aligned packed rows.
+__device__ __forceinline__ uint32_t pack4_i8(uint32_t v) {
+    // four int8 in one dword: code = (value + 1) & 3 per byte; masking to two bits first keeps the per-byte add free
+    // of carries into the neighbouring byte
+    const uint32_t nc = ((v & 0x03030303u) + 0x01010101u) & 0x03030303u;
+    return (nc & 0x3u) | ((nc >> 6) & 0xCu) | ((nc >> 12) & 0x30u) | ((nc >> 18) & 0xC0u);
+}
+
+__global__ void __launch_bounds__(256) pack_i8_fast_kernel(const int8_t* __restrict__ t, int64_t n, int64_t k, int64_t ld_t,
+                                                           uint8_t* __restrict__ pw, int64_t ld_pw) {
+    const int64_t gpr = k / 16, total = n * gpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t row, g;
+        if (total <= 0x7fffffff) { row = (uint32_t)i / (uint32_t)gpr; g = (uint32_t)i - (uint32_t)row * (uint32_t)gpr; }   // 32-bit divide when it fits
+        else { row = i / gpr; g = i - row * gpr; }
+        const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(t + row * ld_t + 16 * g));
+        *reinterpret_cast<uint32_t*>(pw + row * ld_pw + 4 * g) = pack4_i8(v[0]) | (pack4_i8(v[1]) << 8) | (pack4_i8(v[2]) << 16) | (pack4_i8(v[3]) << 24);
+    }
+}
+
 template <typename T> __device__ __forceinline__ T value_as(int v) { return from_float<T>((float)v); }
 
 template <typename T>
@@ -166,6 +188,31 @@ __global__ void __launch_bounds__(256) unpack_kernel(const uint8_t* __restrict__
     }
 }
 
+// Fast path of unpack_kernel: a lane expands 16 / sizeof(T) / 4 packed bytes (f32: 1, f16 / bf16: 2, int8: 4) into ONE
+// 16-byte store, so a wave writes 1 KiB of consecutive bytes; 32-bit index arithmetic when the matrix allows it.
+// Requires k % (4 * bytes per lane) == 0, packed rows aligned to the bytes per lane, 16-byte aligned output rows.
+template <typename T>
+__global__ void __launch_bounds__(256) unpack_fast_kernel(const uint8_t* __restrict__ pw, int64_t n, int64_t k, int64_t ld_pw,
+                                                          T* __restrict__ out, int64_t ld_out) {
+    constexpr int PB = 4 / (int)sizeof(T);   // packed bytes per lane
+    constexpr int NV = 4 * PB;               // values per lane = one 16-byte store
+    const int64_t gpr = k / NV, total = n * gpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t row, g;
+        if (total <= 0x7fffffff) { row = (uint32_t)i / (uint32_t)gpr; g = (uint32_t)i - (uint32_t)row * (uint32_t)gpr; }
+        else { row = i / gpr; g = i - row * gpr; }
+        const uint8_t* src = pw + row * ld_pw + PB * g;
+        uint32_t d;
+        if constexpr (PB == 1) d = *src;
+        else if constexpr (PB == 2) d = *reinterpret_cast<const uint16_t*>(src);
+        else d = *reinterpret_cast<const uint32_t*>(src);
+        T v[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) v[e] = value_as<T>((int)((d >> (2 * e)) & 3u) - 1);
+        *reinterpret_cast<uint4*>(out + row * ld_out + NV * g) = *reinterpret_cast<const uint4*>(v);
+    }
+}
+
 // planar layouts: S = ceil(len/4); byte j holds elements j, S+j, 2S+j, 3S+j
 template <int FORMAT>
 __global__ void __launch_bounds__(256) pack_planar_kernel(const int8_t* __restrict__ t, int64_t len, uint8_t* __restrict__ pw) {
@@ -182,6 +229,38 @@ __global__ void __launch_bounds__(256) pack_planar_kernel(const int8_t* __restri
             b |= (code << (2 * i));
         }
         pw[j] = (uint8_t)b;
+    }
+}
+
+// Fast path of pack_planar_kernel: a lane packs 16 consecutive bytes from four 16-byte loads (one per plane).
+// Requires len == 4 S, S % 16 == 0 and 16-byte aligned buffers.
+template <int FORMAT>
+__global__ void __launch_bounds__(256) pack_planar_fast_kernel(const int8_t* __restrict__ t, int64_t s, uint8_t* __restrict__ pw) {
+    const int64_t groups = s / 16;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+        nt_u32x4 pl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pl[i] = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(t + i * s + 16 * g));
+        nt_u32x4 o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int by = 0; by < 4; ++by) {
+                uint32_t b = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int v = (int)(int8_t)((pl[i][d] >> (8 * by)) & 0xFFu);
+                    uint32_t code;
+                    if constexpr (FORMAT == TVL_PLANAR_A) code = (uint32_t)(v == 1) ^ ((uint32_t)(v == -1) << 1);
+                    else code = (uint32_t)(v + 1) & 0xFFu;  // the reference ORs the whole shifted byte (uint8 arithmetic)
+                    b |= (code << (2 * i));
+                }
+                word |= (b & 0xFFu) << (8 * by);
+            }
+            o[d] = word;
+        }
+        *reinterpret_cast<nt_u32x4*>(pw + 16 * g) = o;
     }
 }
 
@@ -269,6 +348,11 @@ int launch_quantize_pack(const void* w, int w_dtype, int64_t n, int64_t k, int64
 }
 
 int launch_pack_i8(const int8_t* t, int64_t n, int64_t k, int64_t ld_t, uint8_t* pw, int64_t ld_pw, hipStream_t st) {
+    if (k % 16 == 0 && aligned(t, 16) && ld_t % 16 == 0 && aligned(pw, 4) && ld_pw % 4 == 0) {
+        hipLaunchKernelGGL(pack_i8_fast_kernel, dim3(grid_for(n * (k / 16), 256)), dim3(256), 0, st, t, n, k, ld_t, pw, ld_pw);
+        TVL_LAUNCH_CHECK();
+        return TVL_OK;
+    }
     const int vec = aligned(t, 4) && (ld_t % 4 == 0);
     hipLaunchKernelGGL(pack_i8_kernel, dim3(grid_for(n * ceil_div(k, 4), 256)), dim3(256), 0, st, t, n, k, ld_t, pw, ld_pw, vec);
     TVL_LAUNCH_CHECK();
@@ -279,6 +363,19 @@ int launch_unpack(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, void* 
                   hipStream_t st) {
     const dim3 grid(grid_for(n * ceil_div(k, 4), 256)), block(256);
     const size_t es = dtype_size(out_dtype);
+    const int64_t pb = 4 / (int64_t)es;   // packed bytes per lane in the fast kernel
+    if (k % (4 * pb) == 0 && aligned(pw, (size_t)pb) && ld_pw % pb == 0 && aligned(out, 16) && (ld_out * (int64_t)es) % 16 == 0) {
+        const dim3 fgrid(grid_for(n * (k / (4 * pb)), 256));
+        switch (out_dtype) {
+            case TVL_F32: hipLaunchKernelGGL(unpack_fast_kernel<float>, fgrid, block, 0, st, pw, n, k, ld_pw, (float*)out, ld_out); break;
+            case TVL_F16: hipLaunchKernelGGL(unpack_fast_kernel<f16>, fgrid, block, 0, st, pw, n, k, ld_pw, (f16*)out, ld_out); break;
+            case TVL_BF16: hipLaunchKernelGGL(unpack_fast_kernel<bf16_t>, fgrid, block, 0, st, pw, n, k, ld_pw, (bf16_t*)out, ld_out); break;
+            case TVL_I8: hipLaunchKernelGGL(unpack_fast_kernel<int8_t>, fgrid, block, 0, st, pw, n, k, ld_pw, (int8_t*)out, ld_out); break;
+            default: set_error("unpack: unsupported output dtype %d", out_dtype); return TVL_ERR_INVALID;
+        }
+        TVL_LAUNCH_CHECK();
+        return TVL_OK;
+    }
     const int vec = aligned(out, 4 * es) && (ld_out % 4 == 0);
     switch (out_dtype) {
         case TVL_F32: hipLaunchKernelGGL(unpack_kernel<float>, grid, block, 0, st, pw, n, k, ld_pw, (float*)out, ld_out, vec); break;
@@ -292,6 +389,15 @@ int launch_unpack(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, void* 
 }
 
 int launch_pack_planar(const int8_t* t, int64_t len, int format, uint8_t* pw, hipStream_t st) {
+    const int64_t s4 = ceil_div(len, 4);
+    if (format != TVL_PLANAR_A && format != TVL_PLANAR_B) { set_error("unknown planar format %d", format); return TVL_ERR_INVALID; }
+    if (len == 4 * s4 && s4 % 16 == 0 && aligned(t, 16) && aligned(pw, 16)) {
+        const dim3 fgrid(grid_for(s4 / 16, 256));
+        if (format == TVL_PLANAR_A) hipLaunchKernelGGL(pack_planar_fast_kernel<TVL_PLANAR_A>, fgrid, dim3(256), 0, st, t, s4, pw);
+        else hipLaunchKernelGGL(pack_planar_fast_kernel<TVL_PLANAR_B>, fgrid, dim3(256), 0, st, t, s4, pw);
+        TVL_LAUNCH_CHECK();
+        return TVL_OK;
+    }
     const dim3 grid(grid_for(ceil_div(len, 4), 256)), block(256);
     if (format == TVL_PLANAR_A) hipLaunchKernelGGL(pack_planar_kernel<TVL_PLANAR_A>, grid, block, 0, st, t, len, pw);
     else if (format == TVL_PLANAR_B) hipLaunchKernelGGL(pack_planar_kernel<TVL_PLANAR_B>, grid, block, 0, st, t, len, pw);

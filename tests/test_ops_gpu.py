@@ -110,6 +110,10 @@ def test_planar_formats(ops, dev, fmt, golden_dir):
         assert np.array_equal(back.cpu().numpy()[:length].astype(np.int8), t)
     allb = torch.arange(256, dtype=torch.uint8, device=dev)
     assert np.array_equal(ops.unpack_ternary_planar(allb, fmt).cpu().numpy(), unpack(allb.cpu().numpy()))
+    # values outside {-1, 0, +1} pack like the reference's uint8 arithmetic, in the vector kernel (4096) and the scalar one (1000)
+    for length in (4096, 1000):
+        t = np.random.default_rng(length).integers(-128, 128, size=(length,)).astype(np.int8)
+        assert np.array_equal(ops.pack_ternary_planar(torch.from_numpy(t).to(dev), fmt).cpu().numpy(), pack(t))
 
 
 # ------------------------------------------------------------------------------ quantize + pack
@@ -562,7 +566,7 @@ def test_fit_scales_match_reference_golden(ops, dev, golden_dir):
         np.testing.assert_allclose(latent.cpu().numpy(), g[key.replace("__scale", "__latent")], rtol=1e-5, atol=1e-6, err_msg=key)
 
 
-@pytest.mark.parametrize("n,k", [(1, 1), (3, 7), (64, 2048), (300, 1000)])
+@pytest.mark.parametrize("n,k", [(1, 1), (3, 7), (64, 2048), (300, 1000), (9, 4096), (5, 8192), (3, 12288), (6, 1002)])
 def test_fit_ternary_scale_vs_oracle(ops, dev, n, k):
     rng = np.random.default_rng(n + k)
     w = (rng.normal(size=(n, k)) * 0.05).astype(np.float32)
@@ -571,6 +575,12 @@ def test_fit_ternary_scale_vs_oracle(ops, dev, n, k):
         lo, so = O.fit_ternary_scale(w, ns)
         np.testing.assert_allclose(scale.cpu().numpy(), so, rtol=2e-5)
         np.testing.assert_allclose(latent.cpu().numpy(), lo, rtol=2e-5, atol=1e-6)
+    for quant in ("binary", "binary01"):
+        for ns, scaling in (("uniform", "none"), ("independent", "natural"), ("independent", 0.5)):
+            latent, scale = ops.fit_binary_scale(torch.from_numpy(w).to(dev), quant, ns, scaling)
+            lo, so = O.fit_binary_scale(w, quant, ns, scaling)
+            np.testing.assert_allclose(scale.cpu().numpy(), so, rtol=2e-5, atol=1e-9)
+            np.testing.assert_allclose(latent.cpu().numpy(), lo, rtol=4e-5, atol=1e-6)
     with pytest.raises(ValueError):
         ops.fit_binary_scale(torch.from_numpy(w).to(dev), "binary", "none")
 
