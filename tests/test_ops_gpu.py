@@ -533,16 +533,20 @@ def test_matmul_nan_and_inf_like_torch_clip(ops, dev, m, n, k):
     assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(ref, nan=7.0))
 
 
-def test_ternary_mm(ops, dev, golden_dir):
+@pytest.mark.parametrize("method", ["select", "matmul", "auto"])
+def test_ternary_mm(ops, dev, golden_dir, method):
     g = np.load(os.path.join(golden_dir, "ternary_mm.npz"))
     for size in (32, 256):
-        got = ops.ternary_mm(torch.from_numpy(g[f"m{size}"]).to(dev), torch.from_numpy(g[f"tm{size}"]).to(dev))
+        got = ops.ternary_mm(torch.from_numpy(g[f"m{size}"]).to(dev), torch.from_numpy(g[f"tm{size}"]).to(dev), method)
         assert np.array_equal(got.cpu().numpy(), g[f"res{size}"])
-    got = ops.ternary_mm(torch.from_numpy(g["m256r"]).to(dev), torch.from_numpy(g["tm256r"]).to(dev))
+    got = ops.ternary_mm(torch.from_numpy(g["m256r"]).to(dev), torch.from_numpy(g["tm256r"]).to(dev), method)
     assert np.max(np.abs(got.cpu().numpy() - g["res256r"])) <= 1e-4  # float32 order noise at K=256, |sum| ~ 16
     rng = np.random.default_rng(2)
     m, tm = _grid(rng, (37, 101)), rng.normal(size=(19, 101)).astype(np.float32)
-    assert np.array_equal(ops.ternary_mm(torch.from_numpy(m).to(dev), torch.from_numpy(tm).to(dev)).cpu().numpy(), O.ternary_mm(m, tm))
+    tm[3, :7] = [0.0, -0.0, 1e-45, -1e-45, np.inf, -np.inf, np.nan]     # zeros, denormals, infinities, NaN: sign only
+    assert np.array_equal(ops.ternary_mm(torch.from_numpy(m).to(dev), torch.from_numpy(tm).to(dev), method).cpu().numpy(), O.ternary_mm(m, tm))
+    with pytest.raises(ValueError):
+        ops.ternary_mm(torch.from_numpy(m).to(dev), torch.from_numpy(tm).to(dev), "popcount")
 
 
 # ------------------------------------------------------------------------------ scale fits
