@@ -1,0 +1,66 @@
+"""Randomised parity sweep of the fused matmul against the CPU oracle (needs an MI355X).
+
+Shapes are drawn around the dispatch boundaries of the kernels (row counts 1 / 4 / 16 / 32, K multiples of 32 / 64 /
+256 and odd K, channel counts around tile edges), with random choice of activation dtype, output dtype, bias, fused
+activation, the channel the activation starts at, row strides and over-wide packed rows including code 3.  Inputs are
+on the dyadic grid k/64, so every partial sum is exact in float32 and the result must equal the oracle bit for bit
+whatever kernel and summation order the library picks; with the GELU the comparison is at 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ternary_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+M_CHOICES = [1, 2, 3, 4, 5, 8, 15, 16, 17, 31, 32, 33, 63, 64, 100, 129, 255, 256, 257, 300, 513]
+K_CHOICES = [4, 28, 32, 36, 60, 64, 96, 100, 128, 192, 256, 320, 512, 768, 1000, 1024, 1280, 2048, 2080, 4096]
+N_CHOICES = [1, 2, 7, 16, 31, 32, 33, 64, 100, 127, 128, 129, 200, 256, 257, 384, 511, 512, 640, 1000, 2050]
+
+
+def _draw(rng):
+    while True:
+        m, n, k = (int(rng.choice(c)) for c in (M_CHOICES, N_CHOICES, K_CHOICES))
+        if m * n * k <= 3e8:
+            return m, n, k
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_matmul_random_configurations(ops, dev, seed):
+    rng = np.random.default_rng(9000 + seed)
+    for case in range(40):
+        m, n, k = _draw(rng)
+        xdt = [torch.float16, torch.bfloat16, torch.float32][int(rng.integers(0, 3))]
+        ydt = [torch.float32, xdt][int(rng.integers(0, 2))]
+        has_bias, gelu = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
+        act_begin = int(rng.integers(0, n + 1)) if gelu and rng.integers(0, 2) else 0
+        code3 = bool(rng.integers(0, 5) == 0)
+        extra = int(rng.choice([0, 0, 1, 4, 8]))                 # packed rows wider than needed
+        x = rng.integers(-64, 65, size=(m, k)).astype(np.float32) / 64.0
+        kb = (k + 3) // 4
+        if code3:
+            pw = rng.integers(0, 256, size=(n, kb + extra)).astype(np.uint8)
+        else:
+            pw = np.zeros((n, kb + extra), dtype=np.uint8)
+            pw[:, :kb] = O.pack_format_c(rng.integers(-1, 2, size=(n, k)).astype(np.int8))
+            pw[:, kb:] = rng.integers(0, 256, size=(n, extra)).astype(np.uint8)
+        scale = (rng.integers(1, 9, size=(n,)) / 8.0).astype(np.float32) * (0.125 if gelu else 1.0)
+        bias = (rng.integers(-16, 17, size=(n,)) / 8.0).astype(np.float32) if has_bias else None
+        clip = float(rng.choice([100.0, 4.0, 1e6]))
+        want = O.ternary_matmul(x, pw, scale, bias, clip, k=k, act=O.ACT_GELU_TANH if gelu else O.ACT_NONE, act_begin=act_begin)
+        xt = torch.from_numpy(x).to(dev).to(xdt)
+        if rng.integers(0, 3) == 0:                              # rows with a stride (multiple of 8 elements keeps fast paths eligible)
+            pad = int(rng.choice([8, 24, 3]))
+            xt = torch.cat([xt, torch.full((m, pad), 7.0, device=dev, dtype=xdt)], dim=1)[:, :k]
+        got = ops.ternary_matmul(xt, torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev),
+                                 torch.from_numpy(bias).to(dev) if has_bias else None, clip,
+                                 activation="gelu_tanh" if gelu else None, out_dtype=ydt, act_begin=act_begin)
+        tag = f"seed {seed} case {case}: m={m} n={n} k={k} x={xdt} y={ydt} bias={has_bias} gelu={gelu}@{act_begin} code3={code3} extra={extra} clip={clip}"
+        assert got.shape == (m, n) and got.dtype == ydt, tag
+        g = got.float().cpu().numpy()
+        w = torch.from_numpy(want).to(ydt).float().numpy()       # the oracle's float32 result rounded once to the output type
+        if gelu:
+            tol = 1e-5 if ydt == torch.float32 else 2e-2
+            assert np.max(np.abs(g - w)) <= tol, tag
+        else:
+            assert np.array_equal(g, w), tag
