@@ -98,8 +98,10 @@ int tvl_quantize(const void* w, int w_dtype, int64_t numel, int mode, float thre
  * ScaledTernaryLinear.forward at binary/modules.py:101-109.
  * `workspace` (device, may be NULL, 256-byte aligned) lets the library pick kernels that need scratch
  * memory: split-K partial sums, and for float32 activations the three bf16 planes x = hi + mid + lo
- * (exact) that put a float32 product on the matrix cores.  Without it the same results come from
- * slower kernels.  tvl_ternary_matmul_workspace_bytes_for(x_dtype, m, n, k) gives the size that enables
+ * (exact) that put a float32 product on the matrix cores, and - for a k that is not a multiple of 64 or rows
+ * the fast kernels cannot load 16 bytes at a time - zero-padded copies of x and of the packed rows (pad
+ * weights are code 1 = 0), so that those shapes run on the matrix cores as well.  Without it the same
+ * results come from slower kernels.  tvl_ternary_matmul_workspace_bytes_for(x_dtype, m, n, k) gives the size that enables
  * everything; tvl_ternary_matmul_workspace_bytes(m, n, k) is the f16 / bf16 figure.  Contents need no
  * initialisation and are not preserved; calls that share a workspace must be ordered on one stream. */
 int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x,

@@ -470,4 +470,71 @@ int launch_copy_u8(const uint8_t* in, int64_t numel, uint8_t* out, hipStream_t s
     return TVL_OK;
 }
 
+// ---- zero-padded copies along k (for shapes the matrix-core kernels cannot take as they are) ----------------------------------
+// out[m, kp] = x[m, 0..k) followed by zeros; a lane moves 16 bytes (VEC: 16-byte aligned source rows) or fills element by element.
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256) pad_rows_kernel(const T* __restrict__ x, int64_t m, int64_t k, int64_t ld_x, T* __restrict__ out, int64_t kp) {
+    constexpr int PER = 16 / (int)sizeof(T);
+    const int64_t gpr = kp / PER, total = m * gpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t row, g;
+        if (total <= 0x7fffffff) { row = (uint32_t)i / (uint32_t)gpr; g = (uint32_t)i - (uint32_t)row * (uint32_t)gpr; }
+        else { row = i / gpr; g = i - row * gpr; }
+        const int64_t c0 = g * PER;
+        const T* src = x + row * ld_x + c0;
+        T v[PER];
+        if (VEC && c0 + PER <= k) {
+            *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(src);
+        } else {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) v[e] = c0 + e < k ? src[e] : from_float<T>(0.0f);
+        }
+        *reinterpret_cast<uint4*>(out + row * kp + c0) = *reinterpret_cast<const uint4*>(v);
+    }
+}
+
+// out[n, bp] = the packed rows with every code at k and beyond set to 1 (weight 0); a lane writes one dword
+__global__ void __launch_bounds__(256) pad_packed_kernel(const uint8_t* __restrict__ pw, int64_t n, int64_t k, int64_t ld_pw,
+                                                         uint8_t* __restrict__ out, int64_t bp) {
+    const int64_t kb = (k + 3) / 4, gpr = bp / 4, total = n * gpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t row, g;
+        if (total <= 0x7fffffff) { row = (uint32_t)i / (uint32_t)gpr; g = (uint32_t)i - (uint32_t)row * (uint32_t)gpr; }
+        else { row = i / gpr; g = i - row * gpr; }
+        uint32_t d = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t j = 4 * g + e;
+            uint32_t b = j < kb ? pw[row * ld_pw + j] : 0x55u;
+            if (j == kb - 1 && (k & 3)) {
+                const uint32_t keep = (1u << (2 * (k & 3))) - 1u;
+                b = (b & keep) | (0x55u & ~keep);
+            }
+            d |= b << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(out + row * bp + 4 * g) = d;
+    }
+}
+
+int launch_pad_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, void* out, int64_t kp, hipStream_t st) {
+    const size_t es = dtype_size(x_dtype);
+    const bool vec = aligned(x, 16) && (ld_x * (int64_t)es) % 16 == 0;
+    const dim3 grid(grid_for(m * (kp / (16 / (int64_t)es)), 256)), block(256);
+    if (x_dtype == TVL_F32) {
+        if (vec) hipLaunchKernelGGL((pad_rows_kernel<float, true>), grid, block, 0, st, (const float*)x, m, k, ld_x, (float*)out, kp);
+        else hipLaunchKernelGGL((pad_rows_kernel<float, false>), grid, block, 0, st, (const float*)x, m, k, ld_x, (float*)out, kp);
+    } else {   // f16 and bf16 are both moved as 16-bit patterns
+        if (vec) hipLaunchKernelGGL((pad_rows_kernel<f16, true>), grid, block, 0, st, (const f16*)x, m, k, ld_x, (f16*)out, kp);
+        else hipLaunchKernelGGL((pad_rows_kernel<f16, false>), grid, block, 0, st, (const f16*)x, m, k, ld_x, (f16*)out, kp);
+    }
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+int launch_pad_packed(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, uint8_t* out, int64_t bp, hipStream_t st) {
+    hipLaunchKernelGGL(pad_packed_kernel, dim3(grid_for(n * (bp / 4), 256)), dim3(256), 0, st, pw, n, k, ld_pw, out, bp);
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
 }  // namespace tvl

@@ -99,20 +99,64 @@ int tvl_quantize(const void* w, int w_dtype, int64_t numel, int mode, float thre
     return launch_quantize_dense(w, w_dtype, numel, mode, threshold, out, out_dtype, (hipStream_t)stream);
 }
 
-size_t tvl_ternary_matmul_workspace_bytes_for(int x_dtype, int64_t m, int64_t n, int64_t k) {
-    if (m <= 0 || n <= 0 || k <= 0 || k % 64 != 0) return 0;
-    if (x_dtype == TVL_F32) return gemm_mfma_workspace_bytes(TVL_F32, m, n, k);
-    return tvl_ternary_matmul_workspace_bytes(m, n, k);
-}
+// Shapes the matrix-core kernels cannot take as they are (k not a multiple of 64, or rows they cannot load 16 bytes at a
+// time): with enough workspace, x and the packed rows are first copied there zero-padded along k to the next multiple of 64
+// (pad weights are code 1 = 0, pad activations 0, so the sums are unchanged) and the fast kernels run on the copies - two
+// short HBM-bound launches instead of a vector-ALU product that is 20-50x slower on large shapes.
+constexpr double PAD_ROUTE_MIN_WORK = 4.0e6;   // m * n * k below which the generic kernel's single launch is as fast
 
-size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k) {
-    if (m <= 0 || n <= 0 || k <= 0 || k % 64 != 0) return 0;
-    // split-K partial sums for shapes that underfill the chip (the larger of the two kernels' wishes)
+static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+static inline int64_t round_up64(int64_t k) { return (k + 63) / 64 * 64; }
+
+static size_t aligned_workspace_bytes(int x_dtype, int64_t m, int64_t n, int64_t k) {   // k % 64 == 0
+    if (x_dtype == TVL_F32) return gemm_mfma_workspace_bytes(TVL_F32, m, n, k);
+    // split-K partial sums for shapes that underfill the chip (the largest of the kernels' wishes)
     const size_t a = gemm_mfma_workspace_bytes(TVL_F16, m, n, k);
     const size_t b = (m <= 32 && k % 256 == 0) ? gemm_skinny_workspace_bytes(m, n, k) : 0;
     const size_t c = (m <= 16 && k % 256 == 0) ? gemm_stream_workspace_bytes(m, n, k) : 0;
     const size_t ab = a > b ? a : b;
     return ab > c ? ab : c;
+}
+
+static size_t pad_route_bytes(int x_dtype, int64_t m, int64_t n, int64_t k) {
+    const int64_t kp = round_up64(k);
+    return align256((size_t)m * kp * dtype_size(x_dtype)) + align256((size_t)n * (kp / 4)) + aligned_workspace_bytes(x_dtype, m, n, kp);
+}
+
+size_t tvl_ternary_matmul_workspace_bytes_for(int x_dtype, int64_t m, int64_t n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0 || !float_dtype(x_dtype)) return 0;
+    if (k % 64 != 0) return (double)m * (double)n * (double)k >= PAD_ROUTE_MIN_WORK ? pad_route_bytes(x_dtype, m, n, k) : 0;
+    return aligned_workspace_bytes(x_dtype, m, n, k);
+}
+
+size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k) { return tvl_ternary_matmul_workspace_bytes_for(TVL_F16, m, n, k); }
+
+static int dispatch_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                           const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y,
+                           void* workspace, size_t workspace_bytes, hipStream_t st, bool allow_pad) {
+    if (gemv_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
+        return launch_gemv(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+    if (gemm_stream_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
+        return launch_gemm_stream(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
+    if (gemm_skinny_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
+        return launch_gemm_skinny(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
+    if (gemm_mfma_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
+        return launch_gemm_mfma(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
+    if (allow_pad && k > 0 && (double)m * (double)n * (double)k >= PAD_ROUTE_MIN_WORK && workspace && aligned(workspace, 256) &&
+        workspace_bytes >= pad_route_bytes(x_dtype, m, n, k)) {
+        const int64_t kp = round_up64(k);
+        unsigned char* base = static_cast<unsigned char*>(workspace);
+        const size_t xb = align256((size_t)m * kp * dtype_size(x_dtype)), wb = align256((size_t)n * (kp / 4));
+        void* xp = base;
+        uint8_t* pwp = base + xb;
+        int rc = launch_pad_rows(x, x_dtype, m, k, ld_x, xp, kp, st);
+        if (rc != TVL_OK) return rc;
+        rc = launch_pad_packed(pw, n, k, ld_pw, pwp, kp / 4, st);
+        if (rc != TVL_OK) return rc;
+        return dispatch_matmul(xp, x_dtype, m, kp, kp, pwp, n, kp / 4, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, base + xb + wb,
+                               workspace_bytes - xb - wb, st, false);
+    }
+    return launch_gemm_generic(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
 }
 
 int tvl_ternary_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
@@ -148,16 +192,8 @@ int tvl_ternary_matmul_act_from(const void* x, int x_dtype, int64_t m, int64_t k
     TVL_REQUIRE(k == 0 || (x && pw), "ternary_matmul: NULL input pointer");
     TVL_REQUIRE(aligned(x, dtype_size(x_dtype)) && aligned(y, dtype_size(y_dtype)) && aligned(scale, 4) && aligned(bias, 4),
                 "ternary_matmul: misaligned pointer");
-    hipStream_t st = (hipStream_t)stream;
-    if (gemv_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
-        return launch_gemv(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
-    if (gemm_stream_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
-        return launch_gemm_stream(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
-    if (gemm_skinny_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
-        return launch_gemm_skinny(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
-    if (gemm_mfma_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
-        return launch_gemm_mfma(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
-    return launch_gemm_generic(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+    return dispatch_matmul(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes,
+                           (hipStream_t)stream, true);
 }
 
 int tvl_sign_pack_bits(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, uint32_t* xb, int64_t ld_xb, void* stream) {

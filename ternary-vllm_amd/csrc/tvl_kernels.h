@@ -17,6 +17,9 @@ int launch_unpack_planar(const uint8_t* pw, int64_t s, int format, void* out, in
 int launch_quantize_dense(const void* w, int w_dtype, int64_t numel, int mode, float thr, void* out, int out_dtype, hipStream_t st);
 int launch_zero_out(const int32_t* in, int64_t numel, int32_t* out, hipStream_t st);
 int launch_copy_u8(const uint8_t* in, int64_t numel, uint8_t* out, hipStream_t st);
+// zero-padded copies along k: x rows to kp elements (kp % 8 == 0), packed rows to bp bytes (bp % 4 == 0) with pad codes 1 (weight 0)
+int launch_pad_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, void* out, int64_t kp, hipStream_t st);
+int launch_pad_packed(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, uint8_t* out, int64_t bp, hipStream_t st);
 
 // gemm_generic.hip
 int launch_gemm_generic(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,

@@ -217,6 +217,22 @@ def test_matmul_exact_grid(ops, dev, m, n, k, xdt):
     assert torch.equal(got_lp.cpu(), torch.from_numpy(want).to(xdt))
 
 
+@pytest.mark.parametrize("m,n,k", [(300, 500, 1000), (1, 4096, 1000), (16, 700, 2080), (729, 1152, 4304), (40, 90, 1101)])
+@pytest.mark.parametrize("xdt", [torch.float16, torch.bfloat16, torch.float32])
+def test_matmul_k_not_multiple_of_64_padded_route(ops, dev, m, n, k, xdt):
+    """Large shapes with an odd K are zero-padded into the workspace and run on the fast kernels: same bits as the oracle
+    (pad weights are code 1 = 0), also with arbitrary bytes - code 3, junk beyond K - in over-wide packed rows."""
+    rng = np.random.default_rng(m + n + k)
+    x = _grid(rng, (m, k))
+    pw = rng.integers(0, 256, size=(n, (k + 3) // 4 + 5)).astype(np.uint8)
+    scale = rng.uniform(0.5, 1.5, size=(n,)).astype(np.float32)
+    b = rng.normal(size=(n,)).astype(np.float32)
+    want = O.ternary_matmul(x, pw, scale, b, 1e6, k=k)
+    got = ops.ternary_matmul(torch.from_numpy(x).to(dev).to(xdt), torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev),
+                             torch.from_numpy(b).to(dev), 1e6, out_dtype=torch.float32)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("m,n,k", [(9, 40, 52), (130, 257, 256), (300, 512, 512)])
 def test_matmul_no_bias_clip_and_batch_dims(ops, dev, m, n, k):
     rng = np.random.default_rng(k)
