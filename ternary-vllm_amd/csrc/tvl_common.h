@@ -97,7 +97,9 @@ __device__ __forceinline__ float epilogue(float acc, float scale, float bias, fl
 #pragma clang fp contract(off)
     float y = acc * scale;
     if constexpr (HAS_BIAS) y = y + bias;
-    y = (y < -clip) ? -clip : ((y > clip) ? clip : y);  // NaN stays NaN, like torch.clip
+    // IEEE 754-2019 minimum / maximum (v_minimum3_f32 / v_maximum3_f32 on gfx950) propagate NaN, like torch.clip:
+    // two instructions where compare + select needs four
+    y = __builtin_elementwise_maximum(__builtin_elementwise_minimum(y, clip), -clip);
     if constexpr (ACT == TVL_ACT_GELU_TANH) y = gelu_tanh_f32(y);
     return y;
 }
