@@ -36,7 +36,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int BK = 64;             // k elements per pipeline step
 constexpr int ROW_BYTES = BK * 2;  // bytes of one activation row in the LDS tile
-constexpr int NBUF = 3;            // activation tiles in LDS
+constexpr int NBUF = 3;            // activation tiles in LDS (32x32x16 kernel)
+constexpr int BIG_NB = 4;          // activation tiles in LDS of the 256 x 256 kernel (128 KiB)
 constexpr int NUM_CUS = 256;       // MI355X compute units (the cost model and the persistent grid are sized for it)
 
 // ---- 2-bit -> f16 decode -------------------------------------------------------------------
@@ -394,7 +395,10 @@ __device__ __forceinline__ floatx4 mfma16(uint4 a, uint4 b, floatx4 c) {
 // PERSIST: the grid has fewer workgroups than tiles; workgroup b walks tiles b, b + gridDim.x, ... as ONE stream of k
 // steps: the loads of the next tile's first steps are issued during the current tile's last steps and its epilogue
 // (stores are asynchronous), so the per-tile launch / prologue / drain cost is paid once per workgroup, not per tile.
-template <typename TX, typename TY, bool HAS_BIAS, int ACT, int WAVES_M, bool PERSIST>
+// NB = LDS tiles: 3 = a tile is requested one step (~1.3 us) before its use, enough for operands that sit in the
+// Infinity Cache; 4 = two steps ahead (the wait at mid-step leaves the newer group of loads in flight: counted vmcnt),
+// which also covers activations that come cold from HBM.
+template <typename TX, typename TY, bool HAS_BIAS, int ACT, int WAVES_M, bool PERSIST, int NB>
 __global__ void __launch_bounds__(512, 2)
 gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
                    const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act_begin, TY* __restrict__ y,
@@ -406,7 +410,8 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     constexpr int MH = MT / 2, NH = NTL / 2;              // per phase: MH row tiles x NTL channel tiles, NH decodes
     constexpr int A_TILE_BYTES = BM * ROW_BYTES;
     constexpr int ROUNDS = (BM * 8) / NT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NBUF * A_TILE_BYTES
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NB * A_TILE_BYTES
+    static_assert(NB == 3 || NB == 4, "three or four activation tiles in LDS");
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -480,6 +485,12 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     auto wait_loads = [&](uint32_t (&w)[NTL]) {
         if constexpr (NTL == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : : "memory");
+    };
+    // as wait_loads, but the newest group of loads (one step's ROUNDS tile pieces + NTL weight dwords) stays in flight:
+    // loads complete in issue order, so at most that many outstanding means every older load has landed
+    auto wait_loads_keep_newest = [&](uint32_t (&w)[NTL]) {
+        if constexpr (NTL == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(ROUNDS + NTL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(ROUNDS + NTL) : "memory");
     };
 
     const int sw = (c >> 1) & 7;                 // (row >> 1) & 7 with row = 16 i + c
@@ -585,13 +596,14 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         }
     };
 
-    uint32_t bq0[NTL], bq1[NTL], bq2[NTL];   // packed weights (16 per lane and tile) of steps 3j, 3j+1, 3j+2
+    uint32_t bq0[NTL], bq1[NTL], bq2[NTL], bq3[NTL];   // packed weights (16 per lane and tile) of steps NB j, NB j + 1, ...
     uint4 afA[MH], afB[MH], bf0[NTL], bf1[NTL];   // bf0 / bf1: decoded weights of MFMA group s = 0 / 1
     // one step = four phases (s, half of the 16 row tiles); each phase reads the NEXT phase's activation fragments
     // first, then interleaves its 16 MFMAs with the decode of one weight fragment needed two phases later
-    auto step = [&](auto buf_c, uint32_t (&w0)[NTL], uint32_t (&w1)[NTL], uint32_t (&w2)[NTL]) __attribute__((always_inline)) {
+    // w0 / w1: weights of this step and the next; wn: the registers the loads issued in this step (for step + NB - 1) fill
+    auto step = [&](auto buf_c, uint32_t (&w0)[NTL], uint32_t (&w1)[NTL], uint32_t (&wn)[NTL]) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_c)::value;
-        constexpr int buf1 = (buf + 1) % NBUF, buf2 = (buf + 2) % NBUF;
+        constexpr int buf1 = (buf + 1) % NB, bufn = (buf + NB - 1) % NB;
         read_a(buf, 0, 1, afB);
         __builtin_amdgcn_sched_barrier(0);
         decode_part(w0, 1, 0, bf1); mma(afA, 0, bf0);
@@ -603,10 +615,11 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         interleave_hint();
         __builtin_amdgcn_sched_barrier(0);
         // ---- middle of the step: tile kb+1 (and its weights w1) complete, tile kb-1 retired ----
-        wait_loads(w1);
+        if constexpr (NB == 3) wait_loads(w1);
+        else wait_loads_keep_newest(w1);
         __builtin_amdgcn_s_barrier();
         read_a(buf, 1, 1, afB);
-        issue_loads(buf2, w2);
+        issue_loads(bufn, wn);
         __builtin_amdgcn_sched_barrier(0);
         decode_part(w1, 0, 0, bf0); mma(afA, 0, bf1);
         interleave_hint();
@@ -632,28 +645,43 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         }
     };
 
+    // prologue: NB - 1 steps requested (past the last step the cursor re-fetches it, so every count below is constant)
     issue_loads(0, bq0);
-    if (total_steps > 1) issue_loads(1, bq1);
-    else {
+    issue_loads(1, bq1);
+    if constexpr (NB == 4) {
+        issue_loads(2, bq2);
+        wait_loads_keep_newest(bq0);
+        wait_loads_keep_newest(bq1);
+    } else {
+        wait_loads(bq0);
+        wait_loads(bq1);
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) bq1[t] = 0;
+        for (int t = 0; t < NTL; ++t) bq2[t] = 0;
     }
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) bq2[t] = 0;
-    wait_loads(bq0);
-    wait_loads(bq1);
+    for (int t = 0; t < NTL; ++t) bq3[t] = 0;
     __builtin_amdgcn_s_barrier();
     read_a(0, 0, 0, afA);
     decode_part(bq0, 0, 0, bf0);
     decode_part(bq0, 0, 1, bf0);
-    for (int gs = 0; gs < total_steps; gs += NBUF) {
-        step(std::integral_constant<int, 0>{}, bq0, bq1, bq2);
-        if (gs + 1 < total_steps) step(std::integral_constant<int, 1>{}, bq1, bq2, bq0);
-        if (gs + 2 < total_steps) step(std::integral_constant<int, 2>{}, bq2, bq0, bq1);
+    if constexpr (NB == 3) {
+        for (int gs = 0; gs < total_steps; gs += 3) {
+            step(std::integral_constant<int, 0>{}, bq0, bq1, bq2);
+            if (gs + 1 < total_steps) step(std::integral_constant<int, 1>{}, bq1, bq2, bq0);
+            if (gs + 2 < total_steps) step(std::integral_constant<int, 2>{}, bq2, bq0, bq1);
+        }
+    } else {
+        for (int gs = 0; gs < total_steps; gs += 4) {
+            step(std::integral_constant<int, 0>{}, bq0, bq1, bq3);
+            if (gs + 1 < total_steps) step(std::integral_constant<int, 1>{}, bq1, bq2, bq0);
+            if (gs + 2 < total_steps) step(std::integral_constant<int, 2>{}, bq2, bq3, bq1);
+            if (gs + 3 < total_steps) step(std::integral_constant<int, 3>{}, bq3, bq0, bq2);
+        }
     }
     wait_loads(bq0);
     wait_loads(bq1);
     wait_loads(bq2);
+    wait_loads(bq3);
     if constexpr (!PERSIST) store_tile();
 }
 
@@ -736,9 +764,11 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
         if constexpr (BM == 256) {   /* the big tile runs on the 16x16x32 instruction */                            \
             /* 1 x 8 waves; the 2 x 4 layout (WAVES_M = 2: half the LDS reads, twice the weight decode) measured 21 % slower */ \
             const bool persist = nblk > NUM_CUS;   /* more tiles than CUs: one workgroup per CU walks several (+2..7 %) */ \
-            auto k16 = persist ? gemm_mfma16_kernel<TX, TY, HB, ACT, 1, true> : gemm_mfma16_kernel<TX, TY, HB, ACT, 1, false>; \
-            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-            hipLaunchKernelGGL(k16, dim3(persist ? NUM_CUS : nblk), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, \
+            /* the persistent form has no registers left for the fourth weight set (it would spill): three tiles there */ \
+            auto k16 = persist ? gemm_mfma16_kernel<TX, TY, HB, ACT, 1, true, NBUF> : gemm_mfma16_kernel<TX, TY, HB, ACT, 1, false, BIG_NB>; \
+            const size_t lds16 = (size_t)(persist ? NBUF : BIG_NB) * BM * ROW_BYTES;                                \
+            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16)); \
+            hipLaunchKernelGGL(k16, dim3(persist ? NUM_CUS : nblk), block, lds16, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, \
                                bias, clip, act_begin, y, ld_y, tiles_n, nblk, w_steps);                            \
             break;                                                                                                 \
         }                                                                                                          \

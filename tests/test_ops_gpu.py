@@ -531,6 +531,25 @@ def test_matmul_more_tiles_than_cus(ops, dev, m, n, k, xdt):
     assert torch.equal(y16, ref.half())
 
 
+@pytest.mark.parametrize("m,n,k", [(4096, 4096, 64), (4000, 4096, 128), (4096, 3900, 320), (4096, 4096, 576), (3840, 4096, 640), (4096, 3900, 704), (4096, 4096, 768)])
+def test_matmul_one_tile_per_cu_short_k(ops, dev, m, n, k):
+    """192 .. 256 tiles of 256 x 256, one per compute unit, with one to twelve k steps (every remainder modulo four from nine on, where the planner picks this tile): the four-tile LDS pipeline's
+    prologue, its counted waits and its tail (fewer steps than tiles in flight)."""
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    x = torch.randint(-64, 65, (m, k), generator=g).float() / 64.0
+    w = torch.rand(n, k, generator=g) * 2 - 1
+    scale = torch.rand(n, generator=g) + 0.5
+    bias = torch.randn(n, generator=g)
+    pw = ops.ternarize_pack(w.to(dev))
+    ref = torch.clip((x.to(dev) @ ops.unpack_ternary(pw, k).t()) * scale.to(dev) + bias.to(dev), -100.0, 100.0)
+    for xdt in (torch.float16, torch.bfloat16):
+        y = ops.ternary_matmul(x.to(dev).to(xdt), pw, scale.to(dev), bias.to(dev), 100.0, out_dtype=torch.float32)
+        assert torch.equal(y, ref)
+    rows = torch.randint(0, m, (16,), generator=g)
+    want = O.ternary_matmul(x[rows].numpy(), pw.cpu().numpy(), scale.numpy(), bias.numpy(), 100.0)
+    assert np.array_equal(ref[rows.to(dev)].cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("m,n,k", [(300, 512, 256), (2, 64, 64), (20, 100, 52), (4400, 4200, 64)])
 def test_matmul_nan_and_inf_like_torch_clip(ops, dev, m, n, k):
     """NaN activations give NaN outputs (torch.clip keeps NaN, binary/modules.py:107), infinities clip to +-clip_val,
