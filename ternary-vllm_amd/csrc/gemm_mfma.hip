@@ -429,11 +429,16 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         m0 = (tile / tiles_n) * BM; n0 = (tile % tiles_n) * BN;
     }
 
-    const TX* a_src[ROUNDS];
-    const uint8_t* b_src[NTL];
+    // Load addresses = a wave-uniform 64-bit base (tile origin + k step, kept in scalar registers) + a 32-bit per-lane byte
+    // offset inside the tile: half the address registers of 64-bit per-lane pointers and no vector address arithmetic per step.
+    const TX* a_base;
+    const uint8_t* b_base;
+    uint32_t a_off[ROUNDS], b_off[NTL];
     auto set_load_tile = [&](int vb) __attribute__((always_inline)) {
         const int tile = xcd_remap(vb, nblk);
         const int lm0 = (tile / tiles_n) * BM, ln0 = (tile % tiles_n) * BN;
+        a_base = x + (int64_t)lm0 * ld_x;
+        b_base = pw + (int64_t)ln0 * ld_pw;
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
             const int p = i * NT + tid;
@@ -441,13 +446,13 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
             const int chunk = cs ^ ((row >> 1) & 7);
             int gm = lm0 + row;
             gm = gm < m ? gm : m - 1;
-            a_src[i] = x + (int64_t)gm * ld_x + chunk * 8;
+            a_off[i] = (uint32_t)(((int64_t)(gm - lm0) * ld_x + chunk * 8) * (int64_t)sizeof(TX));
         }
 #pragma unroll
         for (int t = 0; t < NTL; ++t) {
             int gn = ln0 + wc * WN + t * 16 + c;
             gn = gn < n ? gn : n - 1;
-            b_src[t] = pw + (int64_t)gn * ld_pw + 4 * q;
+            b_off[t] = (uint32_t)((int64_t)(gn - ln0) * ld_pw + 4 * q);
         }
     };
     set_load_tile(vb_l);
@@ -456,10 +461,10 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + buf * A_TILE_BYTES + (i * NT + wid * 64) * 16);
-            const TX* src = a_src[i] + (int64_t)kb * BK;
+            const TX* sbase = a_base + (int64_t)kb * BK;   // wave-uniform
             uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(a_off[i]), "s"(dst), "s"(sbase) : "memory");
         }
     };
 
@@ -469,7 +474,7 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         kw = kw >= w_steps ? kw - w_steps : kw;
 #pragma unroll
         for (int t = 0; t < NTL; ++t)
-            asm volatile("global_load_dword %0, %1, off" : "=v"(dst[t]) : "v"(b_src[t] + (int64_t)kw * (BK / 4)) : "memory");
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(dst[t]) : "v"(b_off[t]), "s"(b_base + (int64_t)kw * (BK / 4)) : "memory");
     };
     // fetch the cursor's step into LDS buffer `buf` / registers `w`, then advance the cursor (to the next tile of this
     // workgroup after a tile's last step; past the very last step it stays there: harmless re-fetches into a buffer
@@ -903,6 +908,7 @@ bool gemm_mfma_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64
     if (!aligned(pw, 8) || ld_pw % 8 != 0) return false;
     if (m > INT32_MAX || n > INT32_MAX || 3 * k > INT32_MAX) return false;
     if (ceil_div(m, 32) * ceil_div(n, 128) > INT32_MAX) return false;
+    if (ld_x > (1 << 22) || ld_pw > (1 << 22)) return false;   // lane offsets inside a 256-row tile are 32-bit byte offsets
     if (x_dtype == TVL_F32) {   // needs room for the three bf16 planes
         if (!aligned(x, 16) || (ld_x * 4) % 16 != 0) return false;
         return workspace != nullptr && aligned(workspace, 256) && workspace_bytes >= split_bytes(m, k);
