@@ -5,6 +5,8 @@ Shapes are drawn around the dispatch boundaries of the kernels (row counts 1 / 4
 activation, the channel the activation starts at, row strides and over-wide packed rows including code 3.  Inputs are
 on the dyadic grid k/64, so every partial sum is exact in float32 and the result must equal the oracle bit for bit
 whatever kernel and summation order the library picks; with the GELU the comparison is at 1e-5."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -25,7 +27,7 @@ def _draw(rng):
             return m, n, k
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TVL_FUZZ_SEEDS", "6"))))   # more seeds for a longer soak
 def test_matmul_random_configurations(ops, dev, seed):
     rng = np.random.default_rng(9000 + seed)
     for case in range(40):
@@ -64,3 +66,26 @@ def test_matmul_random_configurations(ops, dev, seed):
             assert np.max(np.abs(g - w)) <= tol, tag
         else:
             assert np.array_equal(g, w), tag
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_matmul_random_large_shapes(ops, dev, seed):
+    """Random large shapes (around 200 .. 400 tiles of 256 x 256: one tile per compute unit and the persistent tile loop,
+    ragged edges, 9 .. 24 k steps) against a float32 matmul of the unpacked weights on the same exact-grid inputs, plus
+    a row sample against the CPU oracle."""
+    g = torch.Generator(device="cpu").manual_seed(777 + seed)
+    m = int(torch.randint(3000, 5200, (1,), generator=g))
+    n = int(torch.randint(3000, 5200, (1,), generator=g))
+    k = 64 * int(torch.randint(9, 25, (1,), generator=g))
+    xdt = [torch.float16, torch.bfloat16][seed % 2]
+    x = torch.randint(-64, 65, (m, k), generator=g).float() / 64.0
+    w = torch.rand(n, k, generator=g) * 2 - 1
+    scale = (torch.randint(1, 9, (n,), generator=g) / 8.0).float()
+    bias = (torch.randint(-16, 17, (n,), generator=g) / 8.0).float()
+    pw = ops.ternarize_pack(w.to(dev))
+    y = ops.ternary_matmul(x.to(dev).to(xdt), pw, scale.to(dev), bias.to(dev), 100.0, out_dtype=torch.float32)
+    ref = torch.clip((x.to(dev) @ ops.unpack_ternary(pw, k).t()) * scale.to(dev) + bias.to(dev), -100.0, 100.0)
+    assert torch.equal(y, ref), f"m={m} n={n} k={k} {xdt}"
+    rows = torch.randint(0, m, (8,), generator=g)
+    want = O.ternary_matmul(x[rows].numpy(), pw.cpu().numpy(), scale.numpy(), bias.numpy(), 100.0)
+    assert np.array_equal(y[rows.to(dev)].cpu().numpy(), want)
