@@ -2,6 +2,12 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--m 4096 --n 4096 --k 4096] [--sweep] [--no-cpu]
 
+`--gpus N` with N > 1, started as a plain process, launches N ranks itself (`python -m torch.distributed.run
+--nproc-per-node N bench.py ...` as a child process, before anything touches a GPU), relays rank 0's JSON line and
+exits with the child's status; started by torch.distributed.run (RANK / WORLD_SIZE in the environment) it is one of
+the ranks and refuses to run when WORLD_SIZE differs from --gpus.  `--dry-run` replaces the GPU work by host
+tensors over gloo: the launch, replication, sharding and timing protocol without a GPU (used by the CPU tests).
+
 One step = one `ternary_matmul` (packed {-1,0,+1} weights x f16 activations, fused scale/bias/clip)
 over one synthetic batch resident in HBM: M x K activations against an N x K weight matrix that was
 ternarized and packed once, outside the timed region.  Default workload: 4096 x 4096 x 4096 (the
@@ -141,7 +147,91 @@ def cpu_baseline(m_full, n, k, seed, budget_s=12.0):
             out["select_and_sum_c_port_gops"] = round(2.0 * msel * n * k / dt / 1e9, 2)
     except Exception as e:  # the C port is optional colour; the torch form above is the baseline
         out["select_and_sum_c_port_gops"] = f"unavailable: {e}"
+    # configuration 1: the reference's ternary_mm loop (matrix_mul_tests.py:29-37) as its torch CPU restatement, 1024 x 1024
+    mm_, tm_ = torch.randn(1024, 1024, generator=g), torch.randn(1024, 1024, generator=g)
+    tm_[torch.rand(1024, 1024, generator=g) < 0.5] = 0.0
+    t0 = time.perf_counter()
+    res = torch.zeros(1024, 1024)
+    for i in range(1024):
+        r = tm_[i]
+        res[:, i] = mm_[:, r > 0].sum(dim=1) - mm_[:, r < 0].sum(dim=1)
+    out["ternary_mm_1024_loop_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
     return out
+
+
+def launch_ranks(n):
+    """Start n ranks of this script under torch.distributed.run as a CHILD process (this process has not touched a GPU and
+    never replaces itself), pass the child's output through, and return its exit status."""
+    import socket
+    import subprocess
+    port = 0
+    argv = [{"--m": "--gemm-m", "--n": "--gemm-n", "--k": "--gemm-k"}.get(a, a) for a in sys.argv[1:]]
+    if "--master-port" in argv:
+        i = argv.index("--master-port")
+        port = int(argv[i + 1])
+        del argv[i:i + 2]
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode == 0 and len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 3
+    for ln in lines:
+        print(ln, flush=True)
+    return proc.returncode
+
+
+def dry_run(args, world, rank):
+    """The multi-rank protocol on host tensors over gloo, no GPU and no kernel: rank 0 builds a packed arena (random 2-bit
+    codes: quantize + pack is a GPU kernel), PackedArena.replicate hands it to every rank, rows are assigned by shard_rows,
+    the timed region is bracketed by barriers and reduced by MAX, and rank 0 prints the JSON line with value 0."""
+    import torch.distributed as dist
+    import ternary_vllm_amd as tv
+    from ternary_vllm_amd.conversion import ArenaEntry, PackedArena
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "RANK" not in os.environ:
+        os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_PORT=str(args.master_port or 29533))
+    dist.init_process_group("gloo")
+    M, N, K = args.m, args.n, args.k
+    arena = None
+    if rank == 0:
+        ld = -(-((K + 3) // 4) // 16) * 16
+        g = torch.Generator().manual_seed(1234)
+        arena = PackedArena(torch.randint(0, 171, (N * ld,), dtype=torch.uint8, generator=g), torch.rand(N, generator=g) + 0.5,
+                            torch.randn(N, generator=g), [ArenaEntry("w", N, K, ld, 0, 0, 100.0, True, "ternary")])
+    dist.barrier()
+    t0 = time.perf_counter()
+    arena = PackedArena.replicate(arena, "cpu", src=0)
+    bcast_ms = (time.perf_counter() - t0) * 1e3
+    pw, scale, bias, _ = arena.layer("w")
+    begin, end = tv.shard_rows(M * world, world, rank)
+    sums = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(sums, torch.tensor([float(pw.long().sum()), float(begin), float(end)], dtype=torch.float64))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass                                   # the GPU step would go here
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = all(float(s[0]) == float(sums[0][0]) for s in sums)
+    spans = [(int(s[1]), int(s[2])) for s in sums]
+    ok = ok and spans[0][0] == 0 and spans[-1][1] == M * world and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    if rank == 0:
+        print(json.dumps({"metric": "dry run: multi-rank protocol only", "value": 0.0, "unit": "GOPS", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(float(t.item()) / max(1, args.steps) * 1e3, 6), "dry_run": True,
+                          "ranks_reported": len(sums), "row_spans": spans, "replicated_arena_identical": ok,
+                          "weight_broadcast_ms": round(bcast_ms, 3), "weight_broadcast_bytes": arena.nbytes(), "scaling": "weak"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 4
 
 
 def main():
@@ -149,26 +239,44 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--m", type=int, default=4096)
-    ap.add_argument("--n", type=int, default=4096)
-    ap.add_argument("--k", type=int, default=4096)
+    # (the long spellings exist because torch.distributed.run's own parser rejects "--m" / "--n" as ambiguous abbreviations)
+    ap.add_argument("--m", "--gemm-m", dest="m", type=int, default=4096)
+    ap.add_argument("--n", "--gemm-n", dest="n", type=int, default=4096)
+    ap.add_argument("--k", "--gemm-k", dest="k", type=int, default=4096)
     ap.add_argument("--sweep", action="store_true", help="also time the M sweep and the moondream layer shapes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--x-buffers", type=int, default=0, help="rotating activation / output buffers (default: enough to exceed the Infinity Cache)")
+    ap.add_argument("--no-side", action="store_true", help="skip the side measurements (pack kernel, few-row shapes, float32, vendor GEMM)")
+    ap.add_argument("--dry-run", action="store_true", help="host tensors over gloo, no GPU work: the multi-rank protocol only")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process launches the ranks itself")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        sys.exit(launch_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
+    rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if under_launcher else 0
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        sys.exit(dry_run(args, world, rank))
+
+    # One of the ranks of torch.distributed.run (also with a single rank: the same collectives then run on one GPU).
+    dist = None
+    if under_launcher:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
     import ternary_vllm_amd as tv
+    from ternary_vllm_amd.conversion import PackedArena
     ops = tv.custom_ops_mod
 
     M, N, K = args.m, args.n, args.k
@@ -178,19 +286,20 @@ def main():
     scale = (torch.rand(N, generator=g) + 0.5).to(dev)      # U(0.5, 1.5)
     bias = torch.randn(N, generator=g).to(dev)
 
-    # ---- one-time quantize + pack on rank 0, 2-bit weights broadcast to the other ranks ---------
+    # ---- one-time quantize + pack on rank 0; the 2-bit arena is replicated to the other ranks (the path's only exchange) ----
     extra = {}
-    pw = torch.empty((N, (K + 3) // 4), dtype=torch.uint8, device=dev)
-    if rank == 0:
-        ops.ternarize_pack(w_lat.to(dev), 0.5, out=pw)
-    if world > 1:
-        import torch.distributed as dist
+    arena = PackedArena.from_layers({"w": (w_lat.to(dev), scale, bias, 100.0, "ternary")}, dev) if rank == 0 else None
+    if dist is not None:
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
-        dist.broadcast(pw, src=0); dist.broadcast(scale, src=0); dist.broadcast(bias, src=0)
+        arena = PackedArena.replicate(arena, dev, src=0)
         torch.cuda.synchronize()
         extra["weight_broadcast_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
-        extra["weight_broadcast_bytes"] = pw.numel() + 8 * N
+        extra["weight_broadcast_bytes"] = arena.nbytes()
+    pw, scale, bias, _ = arena.layer("w")
+    # rows of x are independent: the global batch of world * M rows is split evenly, every rank multiplies its own M rows
+    row_begin, row_end = tv.shard_rows(M * world, world, rank)
+    assert row_end - row_begin == M
 
     # ---- synthetic activations: rotate over enough buffers that no step finds its x in a cache: the outputs leave
     # through non-temporal stores and do not occupy the 256 MiB Infinity Cache, so the activation buffers alone must
@@ -199,7 +308,7 @@ def main():
     nbuf = min(nbuf, 64)
     if args.x_buffers > 0:
         nbuf = args.x_buffers
-    gx = torch.Generator().manual_seed(seed + 1 + rank)
+    gx = torch.Generator().manual_seed(seed + 1 + row_begin)
     xs = [(torch.randn(M, K, generator=gx)).to(dev).half() for _ in range(nbuf)]
     ys = [torch.empty((M, N), dtype=torch.float16, device=dev) for _ in range(nbuf)]
 
@@ -214,7 +323,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -223,14 +332,19 @@ def main():
         step(i)
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     event_ms_per_launch = ev0.elapsed_time(ev1) / args.steps   # device time of the timed region itself
-    if world > 1:
+    ranks_reported = 1
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        c = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(c)
+        ranks_reported = int(c.item())
+        assert ranks_reported == args.gpus, f"{ranks_reported} ranks took part, --gpus {args.gpus}"
 
     ops_per_step = 2.0 * M * N * K * world
     value = ops_per_step * args.steps / elapsed / 1e9
@@ -259,7 +373,7 @@ def main():
                "gemm_frac_of_hbm_peak": round(by / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "note": "4096^3 with f16 activations is matrix-core bound (1927 op/B): its HBM fraction is capped near 16 %"}
 
-        if world == 1:   # the side measurements are single-GPU figures; multi-GPU runs report the sharded GEMM only
+        if world == 1 and not args.no_side:   # the side measurements are single-GPU figures; multi-GPU runs report the sharded GEMM only
             # ---- HBM-bound kernel of the path: quantize + pack (f32 in, 2 bits out), cache-cold buffers
             nw = 6  # 6 x 64 MiB of latent weights > 256 MiB Infinity Cache
             wl = [torch.rand(N, K, device=dev) * 2 - 1 for _ in range(nw)]
@@ -271,20 +385,39 @@ def main():
                                   "GBps": round(pack_bytes / (p_avg * 1e-3) / 1e9, 1),
                                   "frac_of_hbm_peak": round(pack_bytes / (p_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del wl, pws
-            # ---- HBM-bound form of the matmul: one activation row (decode), weights streamed once from HBM.
+            # ---- HBM-bound form of the matmul: few activation rows (decode / small batches), weights streamed once from HBM.
             # 16384 x 16384 (64 MiB packed, 10 rotating copies) is large enough to leave the launch-latency regime.
-            for (dn, dk, tag) in ((16384, 16384, "decode_m1_16384"), (N, K, "decode_m1")):
+            for (dm, dn, dk, tag) in ((1, 16384, 16384, "decode_m1_16384"), (1, N, K, "decode_m1"), (16, N, K, "rows16"), (64, N, K, "rows64"),
+                                      (16, 16384, 16384, "rows16_16384"), (64, 16384, 16384, "rows64_16384")):
                 nd = max(2, min(40, (640 << 20) // (dn * dk // 4)))
                 pwd = [torch.randint(0, 171, (dn, dk // 4), dtype=torch.uint8, device=dev) for _ in range(nd)]
-                xd = torch.randn(1, dk, device=dev).half()
-                yd = torch.empty((1, dn), dtype=torch.float16, device=dev)
+                xd = torch.randn(dm, dk, device=dev).half()
+                yd = torch.empty((dm, dn), dtype=torch.float16, device=dev)
                 sd, bd = torch.ones(dn, device=dev), torch.zeros(dn, device=dev)
                 d_avg, d_best, how = time_graph(lambda i: ops.ternary_matmul(xd, pwd[i % nd], sd, bd, 100.0, out=yd), 2 * nd, nd)
-                d_bytes = gemm_bytes(1, dn, dk, 2)
-                hbm[tag] = {"kernel": "tvl::gemv_kernel (one launch: table-lookup decode + v_dot2c, wave-level DPP reduction)", "shape": [1, dn, dk], "timing": how,
-                            "algorithmic_bytes": d_bytes, "avg_call_ms": round(d_avg, 5), "GBps": round(d_bytes / (d_avg * 1e-3) / 1e9, 1),
-                            "frac_of_hbm_peak": round(d_bytes / (d_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                d_bytes = gemm_bytes(dm, dn, dk, 2)
+                hbm[tag] = {"shape": [dm, dn, dk], "timing": how, "algorithmic_bytes": d_bytes, "avg_call_ms": round(d_avg, 5),
+                            "GBps": round(d_bytes / (d_avg * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(d_bytes / (d_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                 del pwd
+
+            # ---- the vendor's dense f16 GEMM (hipBLASLt through torch.matmul) on the same shape, buffers and pre-warm: a yardstick
+            wd = ops.unpack_ternary(pw, K, dtype=torch.float16)
+            for i in range(PREWARM):
+                torch.matmul(xs[i % nbuf], wd.t(), out=ys[i % nbuf])
+            v_avg, v_best = time_launches(lambda i: torch.matmul(xs[i % nbuf], wd.t(), out=ys[i % nbuf]), args.steps, args.warmup, rounds=3)
+            roofline["vendor_dense_f16_ms"] = round(v_avg, 4)
+            roofline["vendor_dense_f16_frac"] = round(flops / (v_avg * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
+            del wd
+
+            # ---- configuration 1: the reference's ternary_mm micro-benchmark (matrix_mul_tests.py: 1024 x 1024, 50 % zeros; 256 x 256)
+            cfg1 = {}
+            for size in (256, 1024):
+                mm_ = torch.randn(size, size, device=dev)
+                tm_ = torch.randn(size, size, device=dev)
+                tm_[torch.rand(size, size, device=dev) < 0.5] = 0.0
+                t_avg, _, how = time_graph(lambda i: ops.ternary_mm(mm_, tm_), 20, 5)
+                cfg1[str(size)] = {"avg_call_ms": round(t_avg, 5), "GOPS": round(2.0 * size ** 3 / (t_avg * 1e-3) / 1e9, 1), "timing": how}
+            extra["config1_ternary_mm"] = cfg1
 
             # ---- the same workload with float32 activations (the reference layer's dtype): three exact bf16 planes on
             # the matrix cores, float32 output
@@ -327,7 +460,7 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{M}x{N}x{K} ternary x f16 GEMM, 2-bit packed weights, fused scale/bias/clip, f16 out",
                        "m_per_gpu": M, "n": N, "k": K, "rotating_activation_buffers": nbuf, "sharding": "rows of x (M) across ranks; packed weights replicated by broadcast"},
-            "roofline": roofline, "hbm": hbm, "prewarm_launches": PREWARM,
+            "roofline": roofline, "hbm": hbm, "prewarm_launches": PREWARM, "ranks_reported": ranks_reported,
         }
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(M, N, K, seed)
@@ -335,7 +468,7 @@ def main():
             result["cpu_baseline"] = None
         result.update(extra)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -10,8 +10,9 @@ What is taken from the reference, by running it:
   * binary/modules.py: tri_step_ste / sign_ste / step_ste (called on tensors
     that require grad - the no-grad branch of those functions raises
     UnboundLocalError), ScaledTernaryLinear / ScaledBinaryLinear /
-    ScaledBinary01Linear forward, linear_to_quantized for all three
-    quantizations and neuron_scale settings.
+    ScaledBinary01Linear forward, SmoothlyBinarizedLinear forward (eval and
+    train), the *_sat quantizers and the SignSTESat module, linear_to_quantized
+    for all four quantizations and the neuron_scale settings.
   * matrix_mul_tests.py: the ternary_mm function only (the module body runs
     100-iteration timings at import, so the function is cut out with ast and
     executed on its own).
@@ -75,7 +76,10 @@ def main():
              x_grid=grid,
              ternary_grid=ref.tri_step_ste(t_grid).detach().numpy(),
              sign_grid=ref.sign_ste(t_grid).detach().numpy(),
-             step_grid=ref.step_ste(t_grid).detach().numpy())
+             step_grid=ref.step_ste(t_grid).detach().numpy(),
+             sign_sat_grid=ref.sign_ste_sat(t_grid).detach().numpy(),
+             step_sat_grid=ref.step_ste_sat(t_grid).detach().numpy(),
+             sign_sat_module_grid=ref.SignSTESat()(t_grid).detach().numpy())
 
     # ---- dense forward of the three scaled layers --------------------------
     # Latent weights on the grid k/64: the straight-through term is then exact, the reference
@@ -122,13 +126,43 @@ def main():
     fwd["ternary_randn_y"] = layer(x.clone()).detach().numpy()
     np.savez(os.path.join(out, "scaled_linear_forward.npz"), **fwd)
 
+    # ---- SmoothlyBinarizedLinear (binary/modules.py:112-146) -----------------
+    # eval: weights binarized by (w >= 0) * 2 - 1, F.linear with the bias, clip.  Grid inputs, grid bias: every
+    # partial sum (bias included, wherever the BLAS adds it) is exact, so the output can be compared bit for bit.
+    # The "_r" case has a random-normal bias and N(0,1) inputs (tolerance).  train: latent weights clipped to [-1, 1].
+    rng_s = np.random.default_rng(4321)   # its own stream: the fixtures generated after this block stay as they were
+    sm = {}
+    for tag, bias, grid in (("bias", True, True), ("nobias", False, True), ("r", True, False)):
+        torch.manual_seed(77)
+        n, k, m = 24, 52, 7
+        layer = ref.SmoothlyBinarizedLinear(k, n, bias=bias, max_val=2.0 if grid else 100.0)
+        with torch.no_grad():
+            if grid:
+                layer.weights.copy_(torch.from_numpy(rng_s.integers(-96, 97, size=(n, k)).astype(np.float32) / 64.0))
+                layer.weights[0, :4] = torch.tensor([0.0, -0.0, 1e-30, -1e-30])
+                if bias:
+                    layer.bias.copy_(torch.from_numpy(rng_s.integers(-16, 17, size=(n,)).astype(np.float32) / 8.0))
+                x = rng_s.integers(-64, 65, size=(m, k)).astype(np.float32) / 64.0
+            else:
+                layer.weights.mul_(1.5)
+                x = rng_s.normal(size=(m, k)).astype(np.float32)
+        sm[f"{tag}_x"] = x
+        sm[f"{tag}_w"] = layer.weights.detach().numpy().copy()
+        if bias:
+            sm[f"{tag}_b"] = layer.bias.detach().numpy().copy()
+        sm[f"{tag}_maxval"] = np.float32(layer.maxval)
+        sm[f"{tag}_y_eval"] = layer.eval()(torch.from_numpy(x.copy())).detach().numpy()
+        sm[f"{tag}_y_train"] = layer.train()(torch.from_numpy(x.copy())).detach().numpy()
+        sm[f"{tag}_converged_1e-1"] = np.int64(layer.count_converged_parameters(1e-1))
+    np.savez(os.path.join(out, "smooth_binary.npz"), **sm)
+
     # ---- linear_to_quantized ------------------------------------------------
     fit = {}
     cases = [("ternary", "uniform", "none"), ("ternary", "independent", "none"), ("ternary", "none", "none"),
              ("binary", "uniform", "none"), ("binary", "independent", "none"), ("binary", "independent", "natural"),
              ("binary", "uniform", "std"), ("binary", "uniform", 0.75),
              ("binary01", "uniform", "none"), ("binary01", "independent", "none"),
-             ("binary01", "independent", "natural")]
+             ("binary01", "independent", "natural"), ("smoothBinary", "uniform", "none")]
     torch.manual_seed(1234)
     lin = nn.Linear(96, 40)
     with torch.no_grad():
@@ -143,6 +177,10 @@ def main():
         q = holder[0]
         tag = f"{quant}__{ns}__{sc}"
         fit[f"{tag}__latent"] = q.weights.detach().numpy().copy()
+        if quant == "smoothBinary":     # no scale parameter (binary/modules.py:267-274)
+            assert type(q).__name__ == "SmoothlyBinarizedLinear" and not hasattr(q, "scale")
+            fit[f"{tag}__bias"] = q.bias.detach().numpy().copy()
+            continue
         fit[f"{tag}__scale"] = q.scale.detach().numpy().copy()
         fit[f"{tag}__bias"] = q.bias.detach().numpy().copy()
     np.savez(os.path.join(out, "linear_to_quantized.npz"), **fit)

@@ -240,6 +240,20 @@ def scaled_linear_forward(x, weights, scale, bias, maxval=100.0, quantization="t
     return np.clip(y, -c, c).reshape(x.shape[:-1] + (q.shape[0],))
 
 
+def smooth_binary_forward(x, weights, bias, maxval=100.0, training=False, acc_dtype=np.float64):
+    """``SmoothlyBinarizedLinear.forward`` (``binary/modules.py:139-146``): evaluation binarizes the latent weights
+    by ``(w >= 0) * 2 - 1`` (``:143``; zero and negative zero give +1), training clips them to [-1, 1] (``:141``);
+    then ``F.linear(x, w, bias)`` and the clip (``:144-145``).  There is no scale parameter."""
+    w = np.asarray(weights, dtype=np.float32)
+    w = np.clip(w, -1.0, 1.0) if training else binarize_sign(w)
+    x = np.asarray(x)
+    y = (x.astype(acc_dtype).reshape(-1, x.shape[-1]) @ w.astype(acc_dtype).T)
+    if bias is not None:
+        y = y + np.asarray(bias, dtype=acc_dtype)[None, :]
+    c = np.float32(abs(maxval))
+    return np.clip(y.astype(np.float32), -c, c).reshape(x.shape[:-1] + (w.shape[0],))
+
+
 def ternary_mm(m: np.ndarray, tm: np.ndarray) -> np.ndarray:
     """Multiplication-free select-and-sum: ``res[:, i] = sum_{tm[i,k]>0} m[:,k] -
     sum_{tm[i,k]<0} m[:,k]``.  ``matrix_mul_tests.py:29-37``.

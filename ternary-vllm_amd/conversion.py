@@ -78,6 +78,12 @@ def to_packed_inference(model: nn.Module, variant: str = "matmul", gelu_names: I
 ROW_ALIGN = 16  # bytes: keeps every layer's rows 16-byte aligned inside the arena
 
 
+def _natural_key(name: str):
+    """Sort key that orders ``h.2.`` before ``h.10.``."""
+    import re
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", name)]
+
+
 @dataclass
 class ArenaEntry:
     name: str
@@ -98,33 +104,41 @@ class PackedArena:
     def __init__(self, packed: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor, entries: List[ArenaEntry]):
         self.packed, self.scales, self.biases = packed, scales, biases
         self.entries = {e.name: e for e in entries}
+        self.skipped: List[str] = []
 
     # -- construction -------------------------------------------------------------------------
     @classmethod
     @torch.no_grad()
-    def from_layers(cls, layers: Mapping[str, Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], float, str]],
-                    device=None) -> "PackedArena":
-        """``layers``: name -> (latent weights [N,K], scale [N], bias [N] | None, maxval, quantization)."""
+    def _build(cls, specs, fetch, device) -> "PackedArena":
+        """``specs``: list of (name, n, k, maxval, has_bias, quantization); ``fetch(name)`` -> (latent weights [n,k],
+        scale [n], bias [n] | None), called once per layer while the arena is filled (one layer resident at a time)."""
         entries, off, voff = [], 0, 0
-        for name, (w, scale, bias, maxval, quant) in layers.items():
-            n, k = w.shape
+        for name, n, k, maxval, has_bias, quant in specs:
             ld = -(-ops.packed_row_bytes(k) // ROW_ALIGN) * ROW_ALIGN
-            entries.append(ArenaEntry(name, n, k, ld, off, voff, float(abs(maxval)), bias is not None, quant))
+            entries.append(ArenaEntry(name, int(n), int(k), ld, off, voff, float(abs(maxval)), bool(has_bias), quant))
             off += n * ld
             voff += n
-        any_w = next(iter(layers.values()))[0]
-        device = device or any_w.device
         packed = torch.full((off,), 0x55, dtype=torch.uint8, device=device)  # pad bytes = four zeros
         scales = torch.empty((voff,), dtype=torch.float32, device=device)
         biases = torch.zeros((voff,), dtype=torch.float32, device=device)
         for e in entries:
-            w, scale, bias, _, quant = layers[e.name]
+            w, scale, bias = fetch(e.name)
+            if tuple(w.shape) != (e.n, e.k) or scale.numel() != e.n or (bias is not None and bias.numel() != e.n):
+                raise ValueError(f"layer {e.name}: weights {tuple(w.shape)}, scale {tuple(scale.shape)} do not match [{e.n}, {e.k}]")
             view = packed[e.offset:e.offset + e.n * e.ld].view(e.n, e.ld)
-            ops.ternarize_pack(w.to(device), 0.5, quant, out=view)
-            scales[e.vec_offset:e.vec_offset + e.n] = scale.to(device, torch.float32)
+            ops.ternarize_pack(w.to(device), 0.5, e.quantization, out=view)
+            scales[e.vec_offset:e.vec_offset + e.n] = scale.to(device, torch.float32).reshape(-1)
             if bias is not None:
-                biases[e.vec_offset:e.vec_offset + e.n] = bias.to(device, torch.float32)
+                biases[e.vec_offset:e.vec_offset + e.n] = bias.to(device, torch.float32).reshape(-1)
         return cls(packed, scales, biases, entries)
+
+    @classmethod
+    def from_layers(cls, layers: Mapping[str, Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], float, str]],
+                    device=None) -> "PackedArena":
+        """``layers``: name -> (latent weights [N,K], scale [N], bias [N] | None, maxval, quantization)."""
+        specs = [(name, w.shape[0], w.shape[1], maxval, bias is not None, quant) for name, (w, _, bias, maxval, quant) in layers.items()]
+        device = device or next(iter(layers.values()))[0].device
+        return cls._build(specs, lambda name: layers[name][:3], device)
 
     @classmethod
     def from_model(cls, model: nn.Module) -> "PackedArena":
@@ -153,6 +167,54 @@ class PackedArena:
         if not layers:
             raise ValueError("no '<prefix>.weights' / '<prefix>.scale' pairs found in the state dict")
         return cls.from_layers(layers, device)
+
+    @classmethod
+    def from_safetensors(cls, path: str, device, start_skip: int = 1, last_skip: int = 0, quantization: str = "ternary",
+                         maxval: float = 100.0, select=None) -> "PackedArena":
+        """Convert a checkpoint written by the reference's training script (``train.py:336-338``) straight from a local
+        ``.safetensors`` file: the counterpart of ``convert.py:70-79`` (quantize the selected layers, then fill their
+        parameters from the file) followed by the pack call of ``utils/conversion.py:61-77``.
+
+        A quantized layer is every prefix with ``<prefix>.weights`` (latent, [N,K]) and ``<prefix>.scale`` ([N]);
+        ``<prefix>.bias`` is optional (``binary/modules.py:96-98``).  Which of them are packed follows
+        ``quantize_moondream`` (``binary/utils.py:14-21``): nothing whose name contains ``lm_head``, nothing in the first
+        ``start_skip`` or last ``last_skip`` blocks ``transformer.h.{i}.`` (the block count is the highest index in the
+        file + 1).  ``select(prefix) -> bool`` replaces that rule.  The file is opened with ``safe_open`` (tensors only,
+        nothing is executed) and read one layer at a time; prefixes the rule left out are listed in ``arena.skipped``."""
+        import re
+
+        from safetensors import safe_open
+        with safe_open(path, framework="pt", device="cpu") as f:
+            keys = set(f.keys())
+            blocks = [int(mo.group(1)) for key in keys for mo in [re.search(r"transformer\.h\.(\d+)\.", key)] if mo]
+            n_blocks = max(blocks) + 1 if blocks else 0
+            from .utils import layers_to_skip
+            skip = layers_to_skip(n_blocks, start_skip, last_skip)
+            rule = select if select is not None else (lambda p: "lm_head" not in p and not any(s_ in p + "." for s_ in skip))
+            specs, skipped = [], []
+            for key in sorted(keys, key=_natural_key):
+                if not key.endswith(".weights"):
+                    continue
+                prefix = key[: -len(".weights")]
+                if prefix + ".scale" not in keys:
+                    continue
+                if not rule(prefix):
+                    skipped.append(prefix)
+                    continue
+                shape = f.get_slice(key).get_shape()
+                if len(shape) != 2:
+                    raise ValueError(f"{key}: expected a 2-D latent weight matrix, got shape {shape}")
+                specs.append((prefix, shape[0], shape[1], maxval, prefix + ".bias" in keys, quantization))
+            if not specs:
+                raise ValueError(f"{path}: no '<prefix>.weights' / '<prefix>.scale' pairs selected")
+
+            def fetch(prefix):
+                return (f.get_tensor(prefix + ".weights"), f.get_tensor(prefix + ".scale"),
+                        f.get_tensor(prefix + ".bias") if prefix + ".bias" in keys else None)
+
+            arena = cls._build(specs, fetch, device)
+        arena.skipped = skipped
+        return arena
 
     # -- use -------------------------------------------------------------------------------------
     def layer(self, name: str):
@@ -195,6 +257,23 @@ class PackedArena:
         import torch.distributed as dist
         for t in (self.packed, self.scales, self.biases):
             dist.broadcast(t, src=src, group=group)
+
+    @classmethod
+    def replicate(cls, arena: Optional["PackedArena"], device, src: int = 0, group=None) -> "PackedArena":
+        """Every rank ends up with rank ``src``'s arena: the index travels as a small object, then the packed bytes,
+        scales and biases as three collectives (RCCL for GPU tensors, gloo for CPU tensors).  ``arena`` is only read on
+        rank ``src``; the other ranks pass ``None``.  This is the one exchange step of the row-sharded multi-GPU mode:
+        weights are quantized and packed once, on one rank, and 2 bits per weight go over the links."""
+        import torch.distributed as dist
+        is_src = dist.get_rank(group) == src
+        if is_src and arena is None:
+            raise ValueError("PackedArena.replicate: the source rank must pass its arena")
+        box = [[e.__dict__ for e in arena.entries.values()] if is_src else None]
+        dist.broadcast_object_list(box, src=src, group=group)
+        entries = [ArenaEntry(**d) for d in box[0]]
+        out = arena if is_src else cls.empty_like_index(entries, device)
+        out.broadcast(src=src, group=group)
+        return out
 
     @classmethod
     def empty_like_index(cls, entries: List[ArenaEntry], device) -> "PackedArena":

@@ -207,6 +207,24 @@ gemm_stream_kernel(const f16* __restrict__ x, int m, int k, int64_t ld_x, const 
             const float sum = acc[0][t][e] * 262144.0f + acc[1][t][e] * 65536.0f;   // 2^18, 2^16: exact scalings
             v[t][e] = sum - sumx;
         }
+    // A non-finite activation breaks the identity sum (c - 1) x = sum c x - sum x: code 0 times infinity is NaN inside the
+    // matrix instruction and the other codes leave infinity - infinity, where the product with the decoded weight is
+    // +-infinity (weight +-1) or NaN (weight 0).  Such a row shows in its sum of x; its outputs are redone here with
+    // decoded weights, one multiply-add per weight straight from memory (rare, so not tuned).
+    if (c < m && !(fabsf(sumx) <= 3.4028234e38f)) {
+        const f16* xr = x + (int64_t)c * ld_x + (int64_t)s0 * 256;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int gn = n0 + 16 * t + 4 * g + e;
+                gn = gn < n ? gn : n - 1;
+                const uint8_t* wr = pw + (int64_t)gn * ld_pw + (int64_t)s0 * 64;
+                float a = 0.0f;
+                for (int kk = 0; kk < ns * 256; ++kk) a += (float)code_value(wr[kk >> 2], kk & 3) * (float)xr[kk];
+                v[t][e] = a;
+            }
+    }
     if constexpr (!SPLIT) {
         const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) | (uintptr_t)(ld_y * (int64_t)sizeof(TY))) & 15) == 0;
 #pragma unroll

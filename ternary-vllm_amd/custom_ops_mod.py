@@ -201,6 +201,8 @@ def _check_pw(pw: torch.Tensor, n: Optional[int], k: int, name: str) -> torch.Te
         raise ValueError(f"{name}: packed weights must be a 2-D uint8 tensor, got {pw.dtype} {tuple(pw.shape)}")
     if pw.shape[1] > 1 and pw.stride(1) != 1:
         raise ValueError(f"{name}: packed weights must have unit stride in the last dimension")
+    if pw.shape[0] > 1 and pw.stride(0) < pw.shape[1]:
+        raise ValueError(f"{name}: packed rows overlap (row stride {pw.stride(0)} < {pw.shape[1]} bytes): pass a dense or row-padded tensor")
     if n is not None and pw.shape[0] != n:
         raise ValueError(f"{name}: packed weights have {pw.shape[0]} rows, expected {n}")
     if pw.shape[1] < packed_row_bytes(k):
@@ -297,8 +299,11 @@ def _planar(fmt: str) -> int:
 _ACTS = {None: ACT_NONE, "none": ACT_NONE, "gelu_tanh": ACT_GELU_TANH, "gelu": ACT_GELU_TANH}
 
 # Split-K scratch memory, one grow-only buffer per (device, stream): calls on one stream are ordered, so
-# they can share it; calls on different streams must not.
+# they can share it; calls on different streams must not.  A buffer that is outgrown is kept alive for the life of
+# the process (`_retired_workspaces`): a HIP graph captured while it was current has its address baked in, and a
+# replay must never write into memory the allocator has meanwhile handed to another tensor.
 _matmul_workspaces = {}
+_retired_workspaces = []
 
 
 _workspace_need = {}
@@ -314,6 +319,9 @@ def _matmul_workspace(device: torch.device, stream: int, x_dtype: int, m: int, n
     key = (device.index, stream)
     ws = _matmul_workspaces.get(key)
     if ws is None or ws.numel() < need:
+        if ws is not None:
+            _retired_workspaces.append(ws)
+            need = max(need, 2 * ws.numel())   # geometric growth bounds what the retired buffers add up to
         ws = torch.empty((need,), dtype=torch.uint8, device=device)
         _matmul_workspaces[key] = ws
     return ws.data_ptr(), ws.numel()
@@ -392,17 +400,25 @@ class PreparedMatmul:
         y2 = self.out.reshape(-1, n)
         self._scale = _vec(scale, n, x.device, "scale")
         self._bias = _vec(bias, n, x.device, "bias") if bias is not None else None
-        self._keep = (x, pw, self.out)
         self._device = x.device
         self._shape = (_dt(x2, "x"), x2.shape[0], n, k)
+        # its own scratch memory, never replaced: safe to capture in a HIP graph on any stream and to replay for as long as
+        # this object lives (two PreparedMatmul objects never share scratch, so they may run on different streams)
+        need = int(_lib.tvl_ternary_matmul_workspace_bytes_for(*self._shape))
+        self._ws = torch.empty((need,), dtype=torch.uint8, device=x.device) if need else None
+        self._keep = (x, pw, self.out, self._ws)
         self._args_head = (x2.data_ptr(), _dt(x2, "x"), x2.shape[0], k, _ld(x2), pw.data_ptr(), n, _ld(pw), self._scale.data_ptr(),
                            self._bias.data_ptr() if self._bias is not None else None, float(clip_val), _ACTS[activation],
                            int(act_begin), y2.data_ptr(), _dt(y2, "out"), _ld(y2))
 
     def __call__(self) -> torch.Tensor:
         stream = int(torch.cuda.current_stream(self._device).cuda_stream)
-        ws_ptr, ws_bytes = _matmul_workspace(self._device, stream, *self._shape)
-        _check(_lib.tvl_ternary_matmul_act_from(*self._args_head, ws_ptr, ws_bytes, stream))
+        ws_ptr, ws_bytes = (self._ws.data_ptr(), self._ws.numel()) if self._ws is not None else (None, 0)
+        if torch.cuda.current_device() == self._device.index:
+            _check(_lib.tvl_ternary_matmul_act_from(*self._args_head, ws_ptr, ws_bytes, stream))
+        else:   # the stream handle belongs to the tensors' device: make it current for the launch
+            with torch.cuda.device(self._device):
+                _check(_lib.tvl_ternary_matmul_act_from(*self._args_head, ws_ptr, ws_bytes, stream))
         return self.out
 
 

@@ -22,7 +22,7 @@ from torch import nn
 
 from . import custom_ops_mod as ops
 
-__all__ = ["tri_step_ste", "sign_ste", "step_ste", "ScaledBinaryLinear", "ScaledBinary01Linear", "ScaledTernaryLinear",
+__all__ = ["tri_step_ste", "sign_ste", "step_ste", "sign_ste_sat", "step_ste_sat", "SignSTESat", "ScaledBinaryLinear", "ScaledBinary01Linear", "ScaledTernaryLinear",
            "SmoothlyBinarizedLinear", "linear_to_quantized"]
 
 
@@ -72,6 +72,14 @@ def step_ste_sat(x: torch.Tensor) -> torch.Tensor:
     return _QuantizeSTE.apply(x, "binary01", True)
 
 
+class SignSTESat(nn.Module):
+    """Module form of :func:`sign_ste_sat` (``binary/modules.py:45-51``): ``(x >= 0) * 2 - 1`` forward, the gradient
+    of ``clip(x, -1, 1)`` backward.  Works with or without ``requires_grad`` (the reference's no-grad branch raises)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return sign_ste_sat(x)
+
+
 # ---------------------------------------------------------------------------------------------------
 # fused forward with a plain-torch backward (training is not the accelerated path)
 # ---------------------------------------------------------------------------------------------------
@@ -110,7 +118,44 @@ class _PackedLinearFn(torch.autograd.Function):
         return gx, gw, gscale, gbias, None, None
 
 
-class _ScaledQuantLinear(nn.Module):
+class _PackedCache:
+    """2-bit packed copy of a layer's latent ``weights``, re-packed when they change.
+
+    The copy is keyed on the parameter's storage address, version counter, device and dtype, which follows every
+    autograd-visible update (optimizer steps, ``copy_``, ``mul_`` ...).  A write through ``.data`` - what the reference's
+    checkpoint loader does, ``p.data[:] = v`` at ``convert.py:78`` - changes neither, so: loading a state dict, switching
+    between ``train()`` and ``eval()`` and ``clip_binary_weights`` drop the copy, a training-mode forward with gradients
+    enabled re-packs on every call (the reference re-quantizes on every call too, ``binary/modules.py:102``), and code
+    that writes ``weights.data`` by hand between two evaluation-mode forwards calls :meth:`invalidate_packed`."""
+
+    quantization = "ternary"
+
+    def _init_packed_cache(self):
+        self._pw: Optional[torch.Tensor] = None
+        self._pw_key = None
+
+    def invalidate_packed(self) -> None:
+        self._pw = None
+        self._pw_key = None
+
+    def packed_weights(self) -> torch.Tensor:
+        w = self.weights
+        key = (w.data_ptr(), w._version, w.device, w.dtype)
+        if self._pw is None or self._pw_key != key or (self.training and torch.is_grad_enabled()):
+            self._pw = ops.ternarize_pack(w.detach(), 0.5, self.quantization)
+            self._pw_key = key
+        return self._pw
+
+    def train(self, mode: bool = True):
+        self.invalidate_packed()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+
+class _ScaledQuantLinear(_PackedCache, nn.Module):
     """Shared body of the three scaled layers: latent ``weights`` [N,K], ``scale`` [N], ``bias`` [N] | None."""
 
     quantization = "ternary"
@@ -121,8 +166,7 @@ class _ScaledQuantLinear(nn.Module):
         self.bias = nn.Parameter(torch.randn(out_features)) if bias else None
         self.scale = nn.Parameter(torch.full((out_features,), 1.0))
         self.maxval = abs(max_val)
-        self._pw: Optional[torch.Tensor] = None
-        self._pw_key = None
+        self._init_packed_cache()
 
     @property
     def in_features(self) -> int:
@@ -131,15 +175,6 @@ class _ScaledQuantLinear(nn.Module):
     @property
     def out_features(self) -> int:
         return self.weights.shape[0]
-
-    def packed_weights(self) -> torch.Tensor:
-        """2-bit packed quantized weights, re-packed only when the latent weights changed."""
-        w = self.weights
-        key = (w.data_ptr(), w._version, w.device, w.dtype)
-        if self._pw is None or self._pw_key != key:
-            self._pw = ops.ternarize_pack(w.detach(), 0.5, self.quantization)
-            self._pw_key = key
-        return self._pw
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         pw = self.packed_weights()
@@ -166,18 +201,19 @@ class ScaledBinary01Linear(_ScaledQuantLinear):
     quantization = "binary01"
 
 
-class SmoothlyBinarizedLinear(nn.Module):
+class SmoothlyBinarizedLinear(_PackedCache, nn.Module):
     """``binary/modules.py:112-146``.  Evaluation: weights binarized by sign, no scale, bias inside the
     clip - one fused packed matmul with unit scale.  Training (latent weights clipped to [-1,1], dense
     matmul, ``:140-141``) stays a dense torch matmul: it has no quantized operand to pack."""
+
+    quantization = "binary"
 
     def __init__(self, in_features: int, out_features: int, bias: bool = True, max_val=100.0):
         super().__init__()
         self.weights = nn.Parameter(torch.randn(out_features, in_features))
         self.bias = nn.Parameter(torch.randn(out_features)) if bias else None
         self.maxval = abs(max_val)
-        self._pw = None
-        self._pw_key = None
+        self._init_packed_cache()
         self._ones = None
 
     def count_converged_parameters(self, eps):
@@ -191,13 +227,10 @@ class SmoothlyBinarizedLinear(nn.Module):
             w = self.weights.clip(-1.0, 1.0)
             y = nn.functional.linear(x, w.to(x.dtype), bias=self.bias.to(x.dtype) if self.bias is not None else None)
             return y.clip(-self.maxval, self.maxval)
-        w = self.weights
-        key = (w.data_ptr(), w._version, w.device, w.dtype)
-        if self._pw is None or self._pw_key != key:
-            self._pw = ops.ternarize_pack(w.detach(), 0.5, "binary")
-            self._pw_key = key
-            self._ones = torch.ones(w.shape[0], dtype=torch.float32, device=w.device)
-        return ops.ternary_matmul(x, self._pw, self._ones, self.bias, self.maxval)
+        pw = self.packed_weights()
+        if self._ones is None or self._ones.device != pw.device:
+            self._ones = torch.ones(pw.shape[0], dtype=torch.float32, device=pw.device)
+        return ops.ternary_matmul(x, pw, self._ones, self.bias, self.maxval)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -70,3 +70,4 @@ def clip_binary_weights(model: nn.Module):
     for mod in model.modules():
         if isinstance(mod, (ScaledBinaryLinear, ScaledBinary01Linear, ScaledTernaryLinear, SmoothlyBinarizedLinear)):
             mod.weights.data = mod.weights.data.clip(-1.0, 1.0)
+            mod.invalidate_packed()

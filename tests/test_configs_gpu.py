@@ -1,0 +1,95 @@
+"""The benchmark configurations at their own shapes, every output element against the C restatement of the reference op.
+
+ViT-Base/16 Dense stack at batch 128 (M = 128 * 197 = 25 216 rows against the four layer shapes), the batch-256 decode
+step of the ternary VLM (M = 256 against Wqkv | fc1 as one packed matrix with the GELU from channel 6144 on, out_proj,
+fc2) and the headline 4096^3 shape.  Inputs are on the dyadic grid k/64, where every partial sum is exact in float32,
+so the HIP result must equal the CPU restatement bit for bit whatever the summation order; N(0,1) inputs are compared
+with the float64 oracle on a row sample."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ternary_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(seed, m, n, k):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(-64, 65, size=(m, k)).astype(np.float32) / 64.0
+    w = rng.uniform(-1, 1, size=(n, k)).astype(np.float32)
+    scale = (rng.integers(4, 13, size=(n,)) / 8.0).astype(np.float32)
+    bias = (rng.integers(-16, 17, size=(n,)) / 8.0).astype(np.float32)
+    return x, w, scale, bias
+
+
+VIT_B16 = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]    # qkv, attention out, mlp fc1, mlp fc2
+
+
+@pytest.mark.parametrize("n,k", VIT_B16)
+def test_vit_base_batch128_full_output(ops, dev, c_oracle, n, k):
+    m = 128 * 197
+    x, w, scale, bias = _problem(n + k, m, n, k)
+    pw = ops.ternarize_pack(torch.from_numpy(w).to(dev))
+    want_pw = O.pack_format_c(O.ternarize(w))
+    assert np.array_equal(pw.cpu().numpy(), want_pw)
+    want = c_oracle(x, want_pw, scale, bias, 100.0)
+    st, bt = torch.from_numpy(scale).to(dev), torch.from_numpy(bias).to(dev)
+    for xdt in (torch.float16, torch.bfloat16):
+        got = ops.ternary_matmul(torch.from_numpy(x).to(dev).to(xdt), pw, st, bt, 100.0, out_dtype=torch.float32)
+        assert np.array_equal(got.cpu().numpy(), want), xdt
+        del got
+    got16 = ops.ternary_matmul(torch.from_numpy(x).to(dev).half(), pw, st, bt, 100.0)      # f16 out: one rounding of the same value
+    assert torch.equal(got16.cpu(), torch.from_numpy(want).half())
+
+
+DECODE_256 = [(6144 + 8192, 2048, 6144), (2048, 2048, 0), (2048, 8192, 0)]   # Wqkv | fc1 (GELU from 6144), out_proj, fc2
+
+
+@pytest.mark.parametrize("n,k,act_begin", DECODE_256)
+@pytest.mark.parametrize("m", [256, 2048])      # batch 256 per GPU; batch 2048 = the eight-GPU configuration on one device
+def test_decode_batch_full_output(ops, dev, c_oracle, m, n, k, act_begin):
+    x, w, scale, bias = _problem(m + n + k, m, n, k)
+    scale *= 0.125
+    pw = ops.ternarize_pack(torch.from_numpy(w).to(dev))
+    want_pw = O.pack_format_c(O.ternarize(w))
+    assert np.array_equal(pw.cpu().numpy(), want_pw)
+    lin = c_oracle(x, want_pw, scale, bias, 100.0)
+    st, bt = torch.from_numpy(scale).to(dev), torch.from_numpy(bias).to(dev)
+    for xdt in (torch.float16, torch.bfloat16):
+        xt = torch.from_numpy(x).to(dev).to(xdt)
+        if act_begin:
+            got = ops.ternary_matmul(xt, pw, st, bt, 100.0, activation="gelu_tanh", act_begin=act_begin, out_dtype=torch.float32).cpu().numpy()
+            assert np.array_equal(got[:, :act_begin], lin[:, :act_begin]), xdt                    # linear channels: bit-exact
+            want_act = O.gelu_tanh(lin[:, act_begin:]).astype(np.float32)                         # float64 tanh, rounded once
+            assert np.max(np.abs(got[:, act_begin:] - want_act)) <= 1e-5, xdt
+        else:
+            got = ops.ternary_matmul(xt, pw, st, bt, 100.0, out_dtype=torch.float32).cpu().numpy()
+            assert np.array_equal(got, lin), xdt
+
+
+def test_headline_4096_full_output_and_randn_rows(ops, dev, c_oracle):
+    """4096 x 4096 x 4096 f16: all 16.7 M outputs against the C restatement on the exact grid, then the benchmark's own
+    data (N(0,1) activations, U(-1,1) latent weights, seed 1234) on a row sample against the float64 oracle, next to
+    the error a float32 CPU evaluation of the same rows makes."""
+    m = n = k = 4096
+    x, w, scale, bias = _problem(4096, m, n, k)
+    w[0, :4] = [0.5, -0.5, 0.4999, -0.4999]
+    pw = ops.ternarize_pack(torch.from_numpy(w).to(dev))
+    want_pw = O.pack_format_c(O.ternarize(w))
+    assert np.array_equal(pw.cpu().numpy(), want_pw)
+    want = c_oracle(x, want_pw, scale, bias, 100.0)
+    st, bt = torch.from_numpy(scale).to(dev), torch.from_numpy(bias).to(dev)
+    got = ops.ternary_matmul(torch.from_numpy(x).to(dev).half(), pw, st, bt, 100.0, out_dtype=torch.float32)
+    assert np.array_equal(got.cpu().numpy(), want)
+    del got, want
+    g = torch.Generator().manual_seed(1235)
+    xr = torch.randn(m, k, generator=g).half()
+    got = ops.ternary_matmul(xr.to(dev), pw, st, bt, 1e6, out_dtype=torch.float32).cpu().numpy()
+    rows = np.random.default_rng(1).integers(0, m, size=48)
+    xs = xr[rows].float().numpy()
+    want64 = O.ternary_matmul(xs, want_pw, scale, bias, 1e6)                       # float64 accumulation
+    cpu32 = c_oracle(xs, want_pw, scale, bias, 1e6)                                # float32 accumulation on the CPU
+    err_gpu, err_cpu = float(np.max(np.abs(got[rows] - want64))), float(np.max(np.abs(cpu32 - want64)))
+    print(f"4096^3 N(0,1) f16: max|gpu - f64| = {err_gpu:.3e}, max|cpu f32 - f64| = {err_cpu:.3e}")
+    assert err_gpu <= max(1e-5, 2.0 * err_cpu)

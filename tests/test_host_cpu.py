@@ -108,9 +108,9 @@ entries, off, voff = [], 0, 0
 for name, (n, k) in shapes.items():
     ld = 16
     entries.append(ArenaEntry(name, n, k, ld, off, voff, 100.0, True, "ternary")); off += n * ld; voff += n
-arena = PackedArena.empty_like_index(entries, "cpu")
-full = {}
+arena = None
 if rank == 0:                                       # rank 0 owns the packed weights
+    arena = PackedArena.empty_like_index(entries, "cpu")
     arena.packed.fill_(0x55)
     for e in entries:
         w = rng.uniform(-1, 1, (e.n, e.k)).astype(np.float32)
@@ -118,9 +118,8 @@ if rank == 0:                                       # rank 0 owns the packed wei
         arena.packed[e.offset:e.offset + e.n * e.ld].view(e.n, e.ld)[:, :pw.shape[1]] = torch.from_numpy(pw)
         arena.scales[e.vec_offset:e.vec_offset + e.n] = torch.from_numpy(rng.uniform(0.5, 1.5, e.n).astype(np.float32))
         arena.biases[e.vec_offset:e.vec_offset + e.n] = torch.from_numpy(rng.normal(size=e.n).astype(np.float32))
-else:
-    arena.packed.zero_(); arena.scales.zero_(); arena.biases.zero_()
-arena.broadcast(src=0)                              # one replication for all layers
+arena = PackedArena.replicate(arena, "cpu", src=0)  # index + one replication for all layers: what bench.py does on N GPUs
+assert list(arena.entries) == ["fc1", "fc2"]
 b, e_ = tv.shard_rows(m, world, rank)               # rows of x are independent: shard them, no collective
 def run(xx):
     pw, s, bi, mv = arena.layer("fc1")
@@ -156,3 +155,45 @@ def test_row_sharded_two_ranks_gloo(tmp_path):
                           "--master-port", "29611", str(script)], env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "SHARD_OK" in out.stdout
+
+
+def _bench(*argv, env=None, timeout=300):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`bench.py --gpus 2` started as a plain process spawns two ranks (torch.distributed.run as a child), which replicate
+    the packed arena from rank 0, take their row shards and report through rank 0: one JSON line with n_gpus == 2.
+    --dry-run: host tensors over gloo, no kernels (the same launch / replicate / shard / barrier + MAX-timing code)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = _bench("--gpus", "2", "--dry-run", "--steps", "4", "--warmup", "1", "--m", "48", "--n", "40", "--k", "100", env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["ranks_reported"] == 2 and r["steps"] == 4 and r["dry_run"] is True
+    assert r["row_spans"] == [[0, 48], [48, 96]] and r["replicated_arena_identical"] is True
+    assert r["weight_broadcast_bytes"] == 40 * 32 + 8 * 40          # rows of 25 bytes padded to 32, scales and biases
+    # a rank count that disagrees with --gpus is refused, not silently reported as something else
+    bad = _bench("--gpus", "4", "--dry-run", env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"))
+    assert bad.returncode == 2 and "WORLD_SIZE=2" in bad.stderr
+    # a failing rank fails the launcher
+    assert _bench("--gpus", "2", "--dry-run", "--steps", "x", env=env).returncode != 0
+
+
+def test_inline_asm_load_audit_is_part_of_the_build():
+    """The matrix-core kernels issue loads from inline asm and complete them with hand-counted waits, which the compiler
+    cannot see: `make` audits the device assembly of the shipped objects and refuses to link on a finding.  Here: the
+    audit target is up to date with the sources (or rebuilds), and every audited kernel reports zero suspicious copies."""
+    csrc = os.path.join(ROOT, "ternary-vllm_amd", "csrc")
+    out = subprocess.run(["make", "-C", csrc, "-j8", "audit"], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "asm audit clean" in out.stdout
+    rules = open(os.path.join(csrc, "Makefile")).read()
+    assert re.search(r"^\$\(OUT\):.*\$\(AUDITS\)", rules, re.M), "the library must depend on the audits"
+    for name, kernel in (("audit_mfma.txt", "gemm_mfma_kernel"), ("audit_mfma16.txt", "gemm_mfma16_kernel"),
+                         ("audit_skinny.txt", "gemm_skinny_kernel"), ("audit_stream.txt", "gemm_stream_kernel")):
+        text = open(os.path.join(csrc, "build", name)).read()
+        assert "TOTAL suspicious copies: 0" in text and kernel in text, name
+        assert len(re.findall(r"load destinations \d+ regs", text)) >= 4, f"{name}: too few kernel instances audited"

@@ -61,6 +61,65 @@ def test_repack_follows_weight_updates(tv, dev):
     assert set(sd) == {"weights", "bias", "scale"}      # checkpoint names of binary/modules.py:96-98
 
 
+def test_data_writes_need_invalidate_and_loads_do_it(tv, dev):
+    """A write through .data (the reference's checkpoint loader, convert.py:78) bumps no version counter: loading a state
+    dict, train() / eval() and invalidate_packed() drop the packed copy; a training-mode forward with gradients re-packs."""
+    torch.manual_seed(0)
+    layer = tv.ScaledTernaryLinear(64, 32).to(dev).eval()
+    x = (torch.randint(-64, 65, (8, 64)).float() / 64).to(dev)
+    new_w = (torch.randint(-64, 65, (32, 64)).float() / 64).to(dev)
+    with torch.no_grad():
+        y0 = layer(x)
+        want = tv.ScaledTernaryLinear(64, 32).to(dev).eval()
+        want.load_state_dict({**layer.state_dict(), "weights": new_w})
+        y_new = want(x)
+        assert not torch.equal(y0, y_new)
+        layer.weights.data[:] = new_w                   # invisible to the cache key
+        layer.invalidate_packed()
+        assert torch.equal(layer(x), y_new)
+        layer.weights.data[:] = -new_w
+        layer.load_state_dict(want.state_dict())        # loading drops the packed copy
+        assert torch.equal(layer(x), y_new)
+        layer.weights.data[:] = -new_w
+        layer.train(); layer.eval()                     # so does switching modes
+        y_neg = layer(x)
+        assert not torch.equal(y_neg, y_new)
+    layer.train()
+    layer.weights.data[:] = new_w
+    assert torch.equal(layer(x).detach(), y_new)        # training forward: re-packed on every call
+
+
+@pytest.mark.parametrize("tag", ["bias", "nobias", "r"])
+def test_smoothly_binarized_linear_matches_reference_golden(tv, dev, golden_dir, tag):
+    """binary/modules.py:139-146: evaluation = sign-binarized weights, bias, clip as ONE packed matmul (bit-equal to the
+    reference's output on the grid cases); training = latent weights clipped to [-1, 1], dense."""
+    g = np.load(os.path.join(golden_dir, "smooth_binary.npz"))
+    n, k = g[f"{tag}_w"].shape
+    bias = tag != "nobias"
+    layer = tv.SmoothlyBinarizedLinear(k, n, bias=bias, max_val=float(g[f"{tag}_maxval"]))
+    assert sorted(n_ for n_, _ in layer.named_parameters()) == (["bias", "weights"] if bias else ["weights"])
+    with torch.no_grad():
+        layer.weights.copy_(torch.from_numpy(g[f"{tag}_w"]))
+        if bias:
+            layer.bias.copy_(torch.from_numpy(g[f"{tag}_b"]))
+    layer = layer.to(dev)
+    x = torch.from_numpy(g[f"{tag}_x"]).to(dev)
+    with torch.no_grad():
+        y_eval = layer.eval()(x).cpu().numpy()
+        y_train = layer.train()(x).cpu().numpy()
+        y_eval16 = layer.eval()(x.half())
+    if tag == "r":
+        assert np.max(np.abs(y_eval - g["r_y_eval"])) <= 1e-5 and np.max(np.abs(y_train - g["r_y_train"])) <= 1e-5
+    else:
+        assert np.array_equal(y_eval, g[f"{tag}_y_eval"])
+        assert np.max(np.abs(y_train - g[f"{tag}_y_train"])) <= 1e-5
+        assert torch.equal(y_eval16.cpu(), torch.from_numpy(g[f"{tag}_y_eval"]).half())
+    want = O.smooth_binary_forward(g[f"{tag}_x"], g[f"{tag}_w"], g[f"{tag}_b"] if bias else None, float(g[f"{tag}_maxval"]))
+    assert np.max(np.abs(y_eval - want)) <= (1e-5 if tag == "r" else 0.0)
+    assert int(layer.count_converged_parameters(1e-1)) == int(g[f"{tag}_converged_1e-1"])
+    assert layer.count_binary_parameters() == n * k
+
+
 def test_training_forward_backward(tv, dev):
     """The layers stay trainable (straight-through estimator); gradients against a dense torch model."""
     torch.manual_seed(1)
@@ -94,6 +153,14 @@ def test_quantizer_functions(tv, dev, golden_dir):
     xs = (x * 2).clone().requires_grad_(True)
     m.sign_ste_sat(xs).sum().backward()
     assert torch.equal(xs.grad, ((xs >= -1) & (xs <= 1)).float())
+    # the saturating forms (binary/modules.py:29-51): same forward values, function and module
+    assert np.array_equal(m.sign_ste_sat(x).cpu().numpy(), g["sign_sat_grid"])
+    assert np.array_equal(m.step_ste_sat(x).cpu().numpy(), g["step_sat_grid"])
+    mod = tv.SignSTESat()
+    assert np.array_equal(mod(x).cpu().numpy(), g["sign_sat_module_grid"])
+    xm = (x * 2).clone().requires_grad_(True)
+    mod(xm).sum().backward()
+    assert torch.equal(xm.grad, xs.grad)
 
 
 def test_linear_to_quantized_matches_reference_golden(tv, dev, golden_dir):
@@ -116,6 +183,20 @@ def test_linear_to_quantized_matches_reference_golden(tv, dev, golden_dir):
         np.testing.assert_allclose(q.scale.detach().cpu().numpy(), g[key], rtol=1e-5, err_msg=key)
         np.testing.assert_allclose(q.weights.detach().cpu().numpy(), g[key.replace("__scale", "__latent")], rtol=1e-5, atol=1e-6, err_msg=key)
         assert np.array_equal(q.bias.detach().cpu().numpy(), g[key.replace("__scale", "__bias")])
+    # smoothBinary: weights and bias copied, no scale (binary/modules.py:267-274); the evaluation forward is the packed matmul
+    holder = nn.Sequential(nn.Linear(96, 40)).to(dev)
+    with torch.no_grad():
+        holder[0].weight.copy_(torch.from_numpy(g["w"]))
+        holder[0].bias.copy_(torch.from_numpy(g["b"]))
+    assert tv.linear_to_quantized(holder, quantization="smoothBinary")
+    q = holder[0]
+    assert type(q).__name__ == "SmoothlyBinarizedLinear" and not hasattr(q, "scale")
+    assert np.array_equal(q.weights.detach().cpu().numpy(), g["smoothBinary__uniform__none__latent"])
+    assert np.array_equal(q.bias.detach().cpu().numpy(), g["smoothBinary__uniform__none__bias"])
+    xg = (torch.randint(-64, 65, (5, 96)).float() / 64)
+    with torch.no_grad():
+        got = q.eval()(xg.to(dev)).cpu().numpy()
+    assert np.max(np.abs(got - O.smooth_binary_forward(xg.numpy(), g["w"], g["b"]))) <= 1e-5
     holder = nn.Sequential(nn.Linear(8, 4)).to(dev)
     with pytest.raises(ValueError):
         tv.linear_to_quantized(holder, quantization="binary", neuron_scale="none")     # modules.py:211-212
@@ -225,6 +306,67 @@ def test_to_packed_inference_and_arena(tv, dev, tmp_path):
         assert torch.equal(blk.mixer.Wqkv(x), want_qkv)
 
 
+def test_arena_from_safetensors_checkpoint(tv, dev, tmp_path):
+    """A reference-style checkpoint file (parameter names of binary/modules.py:96-98 under the moondream module tree) from
+    a local path -> packed arena: the selection rule of binary/utils.py:14-21 by default, every layer's arena bytes equal
+    to the oracle's ternarize + format-C pack, scales and biases verbatim (utils/conversion.py:61-77)."""
+    from safetensors.torch import save_file
+    rng = np.random.default_rng(42)
+    d, n_blocks = 48, 4                                  # K = 48 / 192: packed rows of 12 / 48 bytes, padded to 16 / 48
+    shapes = {"mixer.Wqkv": (3 * d, d), "mixer.out_proj": (d, d), "mlp.fc1": (4 * d, d), "mlp.fc2": (d, 4 * d)}
+    sd = {}
+    for i in range(n_blocks):
+        for name, (n, k) in shapes.items():
+            p = f"text_model.transformer.h.{i}.{name}"
+            w = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+            w.reshape(-1)[:4] = [0.5, -0.5, 0.4999, -0.4999]
+            sd[p + ".weights"] = torch.from_numpy(w)
+            sd[p + ".scale"] = torch.from_numpy(rng.uniform(0.5, 1.5, n).astype(np.float32))
+            if name != "mixer.out_proj":
+                sd[p + ".bias"] = torch.from_numpy(rng.normal(size=n).astype(np.float32))
+        sd[f"text_model.transformer.h.{i}.ln.weight"] = torch.ones(d)
+    sd["text_model.lm_head.linear.weights"] = torch.randn(100, d)      # quantized-looking, but lm_head is never packed
+    sd["text_model.lm_head.linear.scale"] = torch.ones(100)
+    sd["text_model.transformer.embd.wte.weight"] = torch.randn(100, d)
+    path = str(tmp_path / "model.safetensors")
+    save_file(sd, path)
+
+    def check(arena, blocks):
+        want_names = [f"text_model.transformer.h.{i}.{name}" for i in blocks for name in shapes]
+        assert list(arena.entries) == want_names                      # file order by block index, natural sort
+        for p in want_names:
+            e = arena.entries[p]
+            w = sd[p + ".weights"].numpy()
+            pw, scale, bias, maxval = arena.layer(p)
+            want_pw = O.pack_format_c(O.ternarize(w))
+            assert e.ld % 16 == 0 and e.ld >= want_pw.shape[1] and (e.n, e.k) == w.shape
+            got = pw.cpu().numpy()
+            assert np.array_equal(got[:, :want_pw.shape[1]], want_pw), p
+            assert np.all(got[:, want_pw.shape[1]:] == 0x55)          # row padding: code 1 = weight 0
+            assert np.array_equal(scale.cpu().numpy(), sd[p + ".scale"].numpy())
+            if p + ".bias" in sd:
+                assert np.array_equal(bias.cpu().numpy(), sd[p + ".bias"].numpy())
+            else:
+                assert bias is None
+            assert maxval == 100.0
+        return want_names
+
+    arena = tv.PackedArena.from_safetensors(path, dev)                # defaults of quantize_moondream: start_skip=1, last_skip=0
+    names = check(arena, [1, 2, 3])
+    assert sorted(arena.skipped) == sorted([f"text_model.transformer.h.0.{n_}" for n_ in shapes] + ["text_model.lm_head.linear"])
+    check(tv.PackedArena.from_safetensors(path, dev, start_skip=1, last_skip=1), [1, 2])       # convert.py:72
+    check(tv.PackedArena.from_safetensors(path, dev, start_skip=0, last_skip=0), [0, 1, 2, 3])
+    only = tv.PackedArena.from_safetensors(path, dev, select=lambda p: p.endswith("h.2.mlp.fc2"))
+    assert list(only.entries) == ["text_model.transformer.h.2.mlp.fc2"]
+    # the arena multiplies like the layer it came from
+    p = names[2]
+    x = rng.integers(-64, 65, (5, d)).astype(np.float32) / 64
+    want = O.scaled_linear_forward(x, sd[p + ".weights"].numpy(), sd[p + ".scale"].numpy(), sd[p + ".bias"].numpy(), 100.0)
+    assert np.array_equal(arena.matmul(p, torch.from_numpy(x).to(dev)).cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        tv.PackedArena.from_safetensors(path, dev, select=lambda p: False)
+
+
 # ------------------------------------------------------------------------------ decode-loop harness
 
 def test_decode_harness_matches_dense_reference_and_graph_replay(dev):
@@ -298,3 +440,36 @@ def test_prepared_matmul_matches_plain_call(dev):
         assert torch.equal(prep(), ops.ternary_matmul(x, pw, scale, bias, 100.0, activation="gelu_tanh"))
     with pytest.raises(ValueError):
         ops.PreparedMatmul(torch.randn(4, 64, device=dev).half()[:, ::2], pw[:, :8], scale, bias, 100.0)
+    with pytest.raises(ValueError):     # one packed row expanded to many: rows overlap, the kernels would read past the buffer
+        ops.ternary_matmul(x, pw[:1].expand(n, pw.shape[1]), scale, bias, 100.0)
+
+
+def test_workspace_outgrown_after_graph_capture_stays_valid(dev):
+    """A HIP graph captured on a stream keeps the address of that stream's split-K scratch buffer; a later, larger shape
+    on the same stream outgrows the buffer.  The old buffer must stay allocated: the replay still gives the right result
+    after other tensors have been allocated and written."""
+    import ternary_vllm_amd as tv
+    ops = tv.custom_ops_mod
+    torch.manual_seed(11)
+    m, n, k = 12, 512, 16384                       # few rows, long k: split-K through the workspace
+    x = (torch.randint(-64, 65, (m, k), device=dev).float() / 64).half()
+    pw = torch.randint(0, 171, (n, k // 4), dtype=torch.uint8, device=dev)
+    scale, bias = torch.ones(n, device=dev), torch.zeros(n, device=dev)
+    assert ops._lib.tvl_ternary_matmul_workspace_bytes_for(ops.F16, m, n, k) > 0
+    out = torch.empty((m, n), dtype=torch.float32, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.ternary_matmul(x, pw, scale, bias, 1e6, out=out)
+        want = out.clone()
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            ops.ternary_matmul(x, pw, scale, bias, 1e6, out=out)
+        # a much larger split-K shape on the same stream: the stream's buffer is replaced
+        big = ops.ternary_matmul(torch.randn(16, 32768, device=dev).half(), torch.randint(0, 171, (4096, 8192), dtype=torch.uint8, device=dev),
+                                 torch.ones(4096, device=dev), None, 1e6)
+        junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(8)]   # whatever the allocator hands out next
+        out.zero_()
+        graph.replay()
+        s.synchronize()
+    assert torch.equal(out, want) and big.shape == (16, 4096) and len(junk) == 8

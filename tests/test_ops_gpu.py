@@ -550,10 +550,12 @@ def test_matmul_one_tile_per_cu_short_k(ops, dev, m, n, k):
     assert np.array_equal(ref[rows.to(dev)].cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("m,n,k", [(300, 512, 256), (2, 64, 64), (20, 100, 52), (4400, 4200, 64)])
+@pytest.mark.parametrize("m,n,k", [(300, 512, 256), (2, 64, 64), (20, 100, 52), (4400, 4200, 64), (12, 96, 768), (16, 300, 8192), (3, 4096, 4096),
+                                   (24, 256, 512), (40, 512, 1024), (200, 2048, 2048)])
 def test_matmul_nan_and_inf_like_torch_clip(ops, dev, m, n, k):
-    """NaN activations give NaN outputs (torch.clip keeps NaN, binary/modules.py:107), infinities clip to +-clip_val,
-    rows without them are untouched - on every kernel (small tiles, big tile, persistent, generic)."""
+    """NaN activations give NaN outputs (torch.clip keeps NaN, binary/modules.py:107), infinities clip to +-clip_val
+    where the weight is +-1 and give NaN where it is 0 (0 * inf in the reference's dense product), rows without them
+    are untouched - on every kernel (small tiles, big tile, persistent, generic, the few-row kernels with and without split-K)."""
     rng = np.random.default_rng(m + k)
     x, pw, scale, b = _case(rng, m, n, k)
     x[0, 3] = np.nan

@@ -66,6 +66,34 @@ def test_scaled_linear_forward_randn(golden_dir):
     assert np.max(np.abs(y - g["ternary_randn_y"])) < 5e-5
 
 
+def test_smooth_binary_forward(golden_dir):
+    """SmoothlyBinarizedLinear (binary/modules.py:139-146), evaluation and training branches."""
+    g = _npz(golden_dir, "smooth_binary.npz")
+    for tag in ("bias", "nobias"):      # grid inputs, grid bias: exact
+        b = g[f"{tag}_b"] if tag == "bias" else None
+        assert np.array_equal(O.smooth_binary_forward(g[f"{tag}_x"], g[f"{tag}_w"], b, float(g[f"{tag}_maxval"])), g[f"{tag}_y_eval"])
+        assert np.array_equal(O.smooth_binary_forward(g[f"{tag}_x"], g[f"{tag}_w"], b, float(g[f"{tag}_maxval"]), training=True),
+                              g[f"{tag}_y_train"])
+        assert np.max(np.abs(g[f"{tag}_y_eval"])) == float(g[f"{tag}_maxval"])      # the clip is exercised
+        # the evaluation branch as a packed product: sign codes, unit scale, bias inside the clip
+        pw = O.pack_format_c(O.binarize_sign(g[f"{tag}_w"]))
+        n = pw.shape[0]
+        assert np.array_equal(O.ternary_matmul(g[f"{tag}_x"], pw, np.ones(n, np.float32), b, float(g[f"{tag}_maxval"])), g[f"{tag}_y_eval"])
+    assert np.max(np.abs(O.smooth_binary_forward(g["r_x"], g["r_w"], g["r_b"], float(g["r_maxval"])) - g["r_y_eval"])) <= 1e-5
+    assert np.max(np.abs(O.smooth_binary_forward(g["r_x"], g["r_w"], g["r_b"], float(g["r_maxval"]), training=True) - g["r_y_train"])) <= 1e-5
+
+
+def test_saturating_quantizers_have_the_plain_forward_value(golden_dir):
+    """sign_ste_sat / step_ste_sat / SignSTESat (binary/modules.py:29-51) differ from sign_ste / step_ste only in the
+    gradient; where the straight-through term is exact (|x| <= 1 on the grid) the forward values are those of the plain
+    quantizers.  Beyond +-1 the reference adds clip(x) - clip(x).detach() = 0 as well."""
+    g = _npz(golden_dir, "quantizers.npz")
+    xg = g["x_grid"]
+    assert np.array_equal(O.binarize_sign(xg), g["sign_sat_grid"])
+    assert np.array_equal(O.binarize_sign(xg), g["sign_sat_module_grid"])
+    assert np.array_equal(O.binarize_step(xg), g["step_sat_grid"])
+
+
 def test_packed_matmul_equals_dense_forward(golden_dir):
     g = _npz(golden_dir, "scaled_linear_forward.npz")
     for tag, quant in (("ternary_bias", "ternary"), ("binary_bias", "binary"), ("binary01_nobias", "binary01")):
@@ -93,6 +121,8 @@ def test_linear_to_quantized(golden_dir):
             latent, scale = O.fit_binary_scale(w, quant, ns, sc)
         np.testing.assert_allclose(scale, g[key], rtol=2e-6, atol=0, err_msg=key)
         np.testing.assert_allclose(latent, g[key.replace("__scale", "__latent")], rtol=3e-6, atol=1e-7, err_msg=key)
+    # smoothBinary copies the weights and the bias, there is nothing to fit (binary/modules.py:267-274)
+    assert np.array_equal(g["smoothBinary__uniform__none__latent"], w) and np.array_equal(g["smoothBinary__uniform__none__bias"], g["b"])
 
 
 def test_ternary_scale_unknown_neuron_scale_is_per_row():
