@@ -120,6 +120,22 @@ int tvl_ternary_matmul_act_from(const void* x, int x_dtype, int64_t m, int64_t k
 size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k);
 size_t tvl_ternary_matmul_workspace_bytes_for(int x_dtype, int64_t m, int64_t n, int64_t k);
 
+/* tvl_ternary_matmul_act_from for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The scratch memory the other
+ * entry points take as `workspace` is a buffer built into the library instead: TVL_NOALLOC_SCRATCH_BYTES of device
+ * memory per GPU, held until the process ends.  The call allocates and frees nothing (its first use on a GPU looks the
+ * buffer's address up once).  Same results, bit for bit, as tvl_ternary_matmul_act_from given a workspace of
+ * tvl_ternary_matmul_workspace_bytes_for(x_dtype, m, n, k) bytes; a shape that needs more than the built-in buffer is
+ * rejected with TVL_ERR_INVALID and nothing is launched (tvl_noalloc_scratch_bytes() returns the limit).  The device the
+ * pointers live on must be current.  All calls on one GPU share that GPU's buffer: calls that overlap in time on one GPU
+ * (different streams, or threads without ordering) race on it - order them on one stream.  The buffer's contents need
+ * no initialisation and mean nothing between calls. */
+#define TVL_NOALLOC_SCRATCH_BYTES (32u << 20)
+int tvl_ternary_matmul_noalloc(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
+                               int64_t ld_pw, const float* scale, const float* bias, float clip, int act,
+                               int64_t act_begin_channel, void* y, int y_dtype, int64_t ld_y, void* stream);
+size_t tvl_noalloc_scratch_bytes(void);
+
 /* ---- binarized activations (larq `input_quantizer="ste_sign"`, impl/tf/moondream/ternary.py:36) ---- */
 
 /* xb[m, w] bit i = (x[m, 32w+i] >= 0)  (sign_ste, binary/modules.py:5-10: +1 where x >= 0, else -1); pad bits 0.

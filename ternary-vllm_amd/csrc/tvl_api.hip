@@ -2,6 +2,8 @@
 #include "tvl_common.h"
 #include "tvl_kernels.h"
 
+#include <atomic>
+#include <mutex>
 #include <string>
 
 namespace tvl {
@@ -194,6 +196,57 @@ int tvl_ternary_matmul_act_from(const void* x, int x_dtype, int64_t m, int64_t k
                 "ternary_matmul: misaligned pointer");
     return dispatch_matmul(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes,
                            (hipStream_t)stream, true);
+}
+
+}  // extern "C"
+
+// ---- the matmul for callers that cannot allocate ------------------------------------------------------------------
+// Scratch memory of tvl_ternary_matmul_noalloc: a file-scope device array, one copy per GPU, held from the moment the
+// code object is loaded on that GPU until the process ends.  In host code the array's name is only a handle for
+// hipGetSymbolAddress: the address the kernels get is looked up once per device and cached here.
+static __device__ __align__(256) unsigned char scratch[TVL_NOALLOC_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+static std::atomic<void*> g_scratch_ptr[MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+// device address of `scratch` on the CURRENT device (first call on a device: one symbol lookup, no allocation)
+static int current_device_scratch(void** out) {
+    int dev = -1;
+    TVL_HIP_CHECK(hipGetDevice(&dev));
+    TVL_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "ternary_matmul_noalloc: device index %d outside [0, %d)", dev, MAX_DEVICES);
+    void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (p == nullptr) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        p = g_scratch_ptr[dev].load(std::memory_order_relaxed);
+        if (p == nullptr) {
+            TVL_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            TVL_REQUIRE(p != nullptr && aligned(p, 256), "ternary_matmul_noalloc: bad scratch address %p on device %d", p, dev);
+            g_scratch_ptr[dev].store(p, std::memory_order_release);
+        }
+    }
+    *out = p;
+    return TVL_OK;
+}
+
+extern "C" {
+
+size_t tvl_noalloc_scratch_bytes(void) { return TVL_NOALLOC_SCRATCH_BYTES; }
+
+int tvl_ternary_matmul_noalloc(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                               const float* scale, const float* bias, float clip, int act, int64_t act_begin_channel, void* y, int y_dtype,
+                               int64_t ld_y, void* stream) {
+    const size_t need = tvl_ternary_matmul_workspace_bytes_for(x_dtype, m, n, k);
+    TVL_REQUIRE(need <= TVL_NOALLOC_SCRATCH_BYTES,
+                "ternary_matmul_noalloc: m=%lld n=%lld k=%lld (dtype %d) needs %zu bytes of scratch memory, the built-in buffer holds %zu: "
+                "use tvl_ternary_matmul with a caller-owned workspace, or split the rows over several calls",
+                (long long)m, (long long)n, (long long)k, x_dtype, need, (size_t)TVL_NOALLOC_SCRATCH_BYTES);
+    void* ws = nullptr;
+    if (need > 0) {
+        const int rc = current_device_scratch(&ws);
+        if (rc != TVL_OK) return rc;
+    }
+    return tvl_ternary_matmul_act_from(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin_channel, y, y_dtype, ld_y, ws,
+                                       need > 0 ? (size_t)TVL_NOALLOC_SCRATCH_BYTES : 0, stream);
 }
 
 int tvl_sign_pack_bits(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, uint32_t* xb, int64_t ld_xb, void* stream) {

@@ -48,6 +48,9 @@ SIGNATURES = {
                                     _c_int, _c_vp, _c_int, _c_i64, _c_vp, _c_sz, _c_vp]),
     "tvl_ternary_matmul_act_from": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_f32,
                                              _c_int, _c_i64, _c_vp, _c_int, _c_i64, _c_vp, _c_sz, _c_vp]),
+    "tvl_ternary_matmul_noalloc": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_f32,
+                                            _c_int, _c_i64, _c_vp, _c_int, _c_i64, _c_vp]),
+    "tvl_noalloc_scratch_bytes": (_c_sz, []),
     "tvl_ternary_matmul_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tvl_ternary_matmul_workspace_bytes_for": (_c_sz, [_c_int, _c_i64, _c_i64, _c_i64]),
     "tvl_sign_pack_bits": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_vp]),
