@@ -19,710 +19,72 @@
 //    accumulator registers with 16-byte-per-lane stores (v_permlane32_swap between half-waves).
 // Requires k % 64 == 0, 16-byte aligned activation rows and 8-byte aligned packed rows; any m, n
 // (edge tiles clamp their loads and mask their stores).
-#include "tvl_common.h"
-#include "tvl_kernels.h"
+#include "gemm_mfma_kernels.h"
 
-#include <type_traits>
+#include <stdlib.h>
 
 namespace tvl {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-constexpr int BK = 64;             // k elements per pipeline step
-constexpr int ROW_BYTES = BK * 2;  // bytes of one activation row in the LDS tile
-constexpr int NBUF = 3;            // activation tiles in LDS (32x32x16 kernel)
-constexpr int BIG_NB = 4;          // activation tiles in LDS of the 256 x 256 kernel (128 KiB)
-constexpr int NUM_CUS = 256;       // MI355X compute units (the cost model and the persistent grid are sized for it)
-
-// ---- 2-bit -> f16 decode -------------------------------------------------------------------
-// Constants live in registers the compiler cannot see through (set once per kernel by inline asm),
-// so that (rep & mask) | magic becomes ONE v_and_or_b32 instead of v_and + v_or with literals.
-struct DecodeConsts {
-    uint32_t mask01, mask23;  // scalar registers
-    uint32_t magic;           // vector register: 0x6400 in both halves (f16 1024.0)
-};
-__device__ __forceinline__ DecodeConsts make_decode_consts() {
-    DecodeConsts c;
-    asm volatile("s_mov_b32 %0, 0x000C0003" : "=s"(c.mask01));
-    asm volatile("s_mov_b32 %0, 0x00C00030" : "=s"(c.mask23));
-    asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(c.magic));
-    return c;
-}
-
-// `d` holds 16 codes; BYTE selects 4 of them (weights 4*BYTE .. 4*BYTE+3 of the dword).
-// Returns two registers: (w0, w1) and (w2, w3) as packed f16.
-template <int BYTE>
-__device__ __forceinline__ void decode4_f16(uint32_t d, const DecodeConsts& c, uint32_t& r01, uint32_t& r23) {
-    // rep = [byte, 0, byte, 0]: the selected byte in the low 8 bits of both 16-bit halves
-    const uint32_t rep = __builtin_amdgcn_perm(d, d, 0x0C000C00u | BYTE | (BYTE << 16));
-    const uint32_t v01 = (rep & c.mask01) | c.magic;  // lo = 1024 + c0      hi = 1024 + 4 c1
-    const uint32_t v23 = (rep & c.mask23) | c.magic;  // lo = 1024 + 16 c2   hi = 1024 + 64 c3
-    const half2v m01 = {(_Float16)1.0f, (_Float16)0.25f}, a01 = {(_Float16)-1025.0f, (_Float16)-257.0f};
-    const half2v m23 = {(_Float16)0.0625f, (_Float16)0.015625f}, a23 = {(_Float16)-65.0f, (_Float16)-17.0f};
-    const half2v o01 = __builtin_elementwise_fma(__builtin_bit_cast(half2v, v01), m01, a01);
-    const half2v o23 = __builtin_elementwise_fma(__builtin_bit_cast(half2v, v23), m23, a23);
-    r01 = __builtin_bit_cast(uint32_t, o01);
-    r23 = __builtin_bit_cast(uint32_t, o23);
-}
-
-// f16 bit patterns of {-1,0,1,2} -> bf16 bit patterns of the same values, two per register
-__device__ __forceinline__ uint32_t f16pair_to_bf16pair(uint32_t f) { return f | ((f >> 3) & 0x03800380u); }
-
-// 8 weights (one halfword: HW = 0..1 of the dword) -> one MFMA B fragment
-template <typename TX, int HW>
-__device__ __forceinline__ uint4 decode8(uint32_t d, const DecodeConsts& c) {
-    uint4 r;
-    decode4_f16<2 * HW>(d, c, r.x, r.y);
-    decode4_f16<2 * HW + 1>(d, c, r.z, r.w);
-    if constexpr (sizeof(TX) == 2 && !__is_same(TX, f16)) {
-        r.x = f16pair_to_bf16pair(r.x); r.y = f16pair_to_bf16pair(r.y);
-        r.z = f16pair_to_bf16pair(r.z); r.w = f16pair_to_bf16pair(r.w);
-    }
-    return r;
-}
-
-template <typename TX>
-__device__ __forceinline__ floatx16 mfma32(uint4 a, uint4 b, floatx16 c) {
-    if constexpr (__is_same(TX, f16)) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
-    } else {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-}
-
-// XCD-aware tile order: blocks with equal (blockIdx % 8) share an XCD (and its L2) under the
-// observed round-robin placement; give each such group a contiguous run of tiles in row-major
-// order so that a group streams whole activation row panels once.  Bijective for any grid size.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
-    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    return start + i;
-}
-
-// SPLIT = true: blockIdx.y selects a range of k steps; the raw float32 partial sums of that range go
-// to slab blockIdx.y of `y` (float [splits][m][ld_y]) and splitk_reduce_kernel finishes the job.
-template <typename TX, typename TY, int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_BIAS, int ACT, bool SPLIT>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
-gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
-                 const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act_begin, TY* __restrict__ y,
-                 int64_t ld_y, int tiles_n, int nblk, int steps_per_split, int w_steps) {
-    constexpr int NT = 64 * WAVES_M * WAVES_N;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
-    constexpr int TM = WM / 32, TN = WN / 32;            // 32x32 MFMA tiles per wave
-    constexpr int A_TILE_BYTES = BM * ROW_BYTES;
-    constexpr int ROUNDS = (BM * 8) / NT;                // 16-byte pieces per thread per tile
-    static_assert((BM * 8) % NT == 0, "tile/threads mismatch");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NBUF * A_TILE_BYTES
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wr = wid / WAVES_N, wc = wid % WAVES_N;
-    const int tile = xcd_remap(blockIdx.x, nblk);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-
-    // ---- activation staging addresses (per thread, constant over k) ----------------------
-    const TX* a_src[ROUNDS];
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-        const int p = i * NT + tid;           // 16-byte piece index inside the tile image
-        const int row = p >> 3, cs = p & 7;   // LDS row, swizzled chunk
-        const int chunk = cs ^ ((row >> 1) & 7);
-        int gm = m0 + row;
-        gm = gm < m ? gm : m - 1;
-        a_src[i] = x + (int64_t)gm * ld_x + chunk * 8;
-    }
-    const int total_steps = k / BK;
-    const int kb0 = SPLIT ? (int)blockIdx.y * steps_per_split : 0;   // first k step of this block
-    const int nk = SPLIT ? (total_steps - kb0 < steps_per_split ? total_steps - kb0 : steps_per_split) : total_steps;
-    if constexpr (SPLIT) {
-        y += (int64_t)blockIdx.y * m * ld_y;
-#pragma unroll
-        for (int i = 0; i < ROUNDS; ++i) a_src[i] += (int64_t)kb0 * BK;
-    }
-    // LDS-DMA issued from inline asm: hipcc then neither counts it nor orders the fragment reads of
-    // the OTHER buffer behind it (with the builtin it drains vmcnt(0) before the first ds_read of every
-    // step, which serialises load and compute).  Completion is waited for by hand: every wave's
-    // s_waitcnt vmcnt(0) at the top of the next step, then the barrier.
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
-    auto stage_a = [&](int kb, int buf) {
-#pragma unroll
-        for (int i = 0; i < ROUNDS; ++i) {
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + buf * A_TILE_BYTES + (i * NT + wid * 64) * 16);
-            const TX* src = a_src[i] + (int64_t)kb * BK;
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-        }
-    };
-
-    // ---- packed weight addresses ------------------------------------------------------------
-    const uint8_t* b_src[TN];
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        int gn = n0 + wc * WN + t * 32 + r;
-        gn = gn < n ? gn : n - 1;
-        b_src[t] = pw + (int64_t)gn * ld_pw + 8 * h;
-    }
-
-    // ---- fragment read offsets -----------------------------------------------------------------
-    const int sw = (r >> 1) & 7;
-    const int a_row_off = (wr * WM + r) * ROW_BYTES;
-    int a_col_off[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a_col_off[s] = ((4 * h + s) ^ sw) * 16;
-
-    floatx16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int t = 0; t < TN; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.0f;
-
-    const DecodeConsts dc = make_decode_consts();
-
-    // Pipeline (NBUF = 3 LDS tiles): at the middle of step kb every wave waits for its own pieces of
-    // tile kb+1 (issued a whole step earlier), one barrier publishes them and retires all reads of
-    // tile kb-1, whose buffer tile kb+2 is then loaded into.  Fragments (LDS reads and weight decode)
-    // are fetched one 16-deep sub-step ahead of the MFMAs that use them, across step boundaries, so
-    // the matrix pipe never drains at the barrier.
-    // All loads of the loop are issued from inline asm and waited for by hand (one s_waitcnt vmcnt(0) per
-    // step): hipcc's own counted waits only see the loads it emitted and would drain the LDS-DMA queue
-    // early.  The wait statement names the weight registers it completes ("+v"), which orders every
-    // consumer behind it.  The loop is unrolled by NBUF so that buffers and registers have static roles
-    // (no rotation copies of registers whose loads are still in flight).
-    uint64_t bq0[TN], bq1[TN], bq2[TN];  // packed weights (32 per lane and tile) of steps 3j, 3j+1, 3j+2
-    // The packed rows hold w_steps k steps; a k range longer than that re-reads them from the start (float32
-    // activations arrive as three bf16 planes side by side along k: the same weights multiply each plane).
-    auto load_b = [&](int kb, uint64_t (&dst)[TN]) {
-        int kw = kb0 + kb;
-        kw = kw >= w_steps ? kw - w_steps : kw;
-        kw = kw >= w_steps ? kw - w_steps : kw;
-#pragma unroll
-        for (int t = 0; t < TN; ++t)
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[t]) : "v"(b_src[t] + (int64_t)kw * (BK / 4)) : "memory");
-    };
-    auto wait_loads = [&](uint64_t (&q)[TN]) {
-        if constexpr (TN == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]) : : "memory");
-        else if constexpr (TN == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]) : : "memory");
-        else static_assert(TN <= 2, "extend wait_loads");
-    };
-    auto read_a = [&](int buf, int s, uint4 (&af)[TM]) {
-        const unsigned char* abase = lds + buf * A_TILE_BYTES + a_row_off + a_col_off[s];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(abase + i * 32 * ROW_BYTES);
-    };
-    auto decode_b = [&](const uint64_t (&bq)[TN], int s, uint4 (&bf)[TN]) {
-#pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            const uint32_t d = (s < 2) ? (uint32_t)bq[t] : (uint32_t)(bq[t] >> 32);
-            bf[t] = (s & 1) ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc);
-        }
-    };
-    auto mma = [&](const uint4 (&af)[TM], const uint4 (&bf)[TN]) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int t = 0; t < TN; ++t) acc[i][t] = mfma32<TX>(bf[t], af[i], acc[i][t]);
-    };
-
-    // scheduling hint for one sub-step: each MFMA followed by up to VALU_PER_MFMA vector instructions
-    auto interleave_hint = [&]() {
-        constexpr int VALU_PER_MFMA = (10 * TN + 2 + TM * TN - 1) / (TM * TN) + 1;
-#pragma unroll
-        for (int j = 0; j < TM * TN; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // decode / address VALU
-        }
-    };
-
-    uint4 afA[TM], bfA[TN], afB[TM], bfB[TN];
-    // one step; buf = kb % NBUF is a compile-time constant, q0/q1/q2 = weights of steps kb, kb+1, kb+2
-    auto step = [&](int kb, auto buf_c, uint64_t (&q0)[TN], uint64_t (&q1)[TN], uint64_t (&q2)[TN]) {
-        constexpr int buf = decltype(buf_c)::value;
-        constexpr int buf1 = (buf + 1) % NBUF, buf2 = (buf + 2) % NBUF;
-        // Each 16-deep sub-step: the 4 (TM) LDS reads of the NEXT sub-step's activation fragments go
-        // first (pinned by sched_barrier so they cannot sink to their use), then the 8 (TM*TN) MFMAs of
-        // the CURRENT sub-step are interleaved with the decode of the next weight fragments.
-        read_a(buf, 1, afB);
-        __builtin_amdgcn_sched_barrier(0);
-        decode_b(q0, 1, bfB); mma(afA, bfA);
-        interleave_hint();
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(buf, 2, afA);
-        __builtin_amdgcn_sched_barrier(0);
-        decode_b(q0, 2, bfA); mma(afB, bfB);
-        interleave_hint();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- middle of the step: tile kb+1 (and its weights q1) complete, tile kb-1 retired ----
-        wait_loads(q1);
-        __builtin_amdgcn_s_barrier();
-        // branch-free tail: past the end the loads re-fetch the last tile into a buffer nobody reads
-        // again and the prefetched fragments are never used
-        const int kn = kb + 2 < nk ? kb + 2 : nk - 1;
-        read_a(buf, 3, afB);
-        stage_a(kn, buf2); load_b(kn, q2);
-        __builtin_amdgcn_sched_barrier(0);
-        decode_b(q0, 3, bfB); mma(afA, bfA);
-        interleave_hint();
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(buf1, 0, afA);
-        __builtin_amdgcn_sched_barrier(0);
-        decode_b(q1, 0, bfA); mma(afB, bfB);
-        interleave_hint();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    stage_a(0, 0);
-    load_b(0, bq0);
-    if (nk > 1) { stage_a(1, 1); load_b(1, bq1); }
-    else {
-#pragma unroll
-        for (int t = 0; t < TN; ++t) bq1[t] = 0;
-    }
-#pragma unroll
-    for (int t = 0; t < TN; ++t) bq2[t] = 0;
-    wait_loads(bq0);
-    wait_loads(bq1);
-    __builtin_amdgcn_s_barrier();
-    read_a(0, 0, afA);
-    decode_b(bq0, 0, bfA);
-    for (int kb = 0; kb < nk; kb += NBUF) {
-        step(kb, std::integral_constant<int, 0>{}, bq0, bq1, bq2);
-        if (kb + 1 < nk) step(kb + 1, std::integral_constant<int, 1>{}, bq1, bq2, bq0);
-        if (kb + 2 < nk) step(kb + 2, std::integral_constant<int, 2>{}, bq2, bq0, bq1);
-    }
-    // Drain before leaving the loop: no LDS-DMA may outlive the workgroup's LDS allocation, and the
-    // destination registers of the last (unused) weight loads must stay reserved until the data has
-    // landed - a register freed earlier could be reused and then overwritten by the late load.
-    wait_loads(bq0);
-    wait_loads(bq1);
-    wait_loads(bq2);
-
-    // ---- epilogue ---------------------------------------------------------------------------------
-    // The weights are the MFMA "A" operand, so a lane owns ONE activation row m = .. + r and, per
-    // accumulator register group q = e >> 2, four consecutive output channels n = .. + 8q + 4h + (e & 3).
-    // 16/32-bit outputs: one v_permlane32_swap per register pair hands lanes 0-31 the upper half-wave's
-    // channels of group q and lanes 32-63 the lower half-wave's channels of group q+1, so every lane
-    // stores 16 contiguous bytes (8x fewer store instructions than one element per lane).
-    const float c = fabsf(clip);
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) | (uintptr_t)(ld_y * (int64_t)sizeof(TY))) & 15) == 0;
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int nb = n0 + wc * WN + t * 32;  // first channel of this 32-wide tile
-        float sc[16], bi[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int gn = nb + (e & 3) + 8 * (e >> 2) + 4 * h;
-            sc[e] = (!SPLIT && gn < n) ? scale[gn] : 0.0f;
-            bi[e] = (!SPLIT && HAS_BIAS && gn < n) ? bias[gn] : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int gm = m0 + wr * WM + i * 32 + r;
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                v[e] = SPLIT ? acc[i][t][e] : epilogue_ch<HAS_BIAS, ACT>(acc[i][t][e], sc[e], bi[e], c, nb + (e & 3) + 8 * (e >> 2) + 4 * h, act_begin);
-            TY* yrow = y + (int64_t)(gm < m ? gm : 0) * ld_y;
-            if (vec_ok && nb + 32 <= n) {
-                if (gm < m) {
-                    if constexpr (sizeof(TY) == 4) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            *reinterpret_cast<float4*>(yrow + nb + 8 * q + 4 * h) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-                    }
-                }
-                if constexpr (sizeof(TY) == 2) {
-                    // pack 4 channels -> 8 bytes per group, then swap halves between register pairs
-                    uint2 pk[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        TY tmp[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) tmp[j] = from_float<TY>(v[4 * q + j]);
-                        pk[q] = *reinterpret_cast<const uint2*>(tmp);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q += 2) {
-                        // all 64 lanes take part in the swap (no divergence above this point)
-                        auto sx = __builtin_amdgcn_permlane32_swap(pk[q].x, pk[q + 1].x, false, false);
-                        auto sy = __builtin_amdgcn_permlane32_swap(pk[q].y, pk[q + 1].y, false, false);
-                        // lanes 0-31: [own group q | upper half's group q]; lanes 32-63: [lower half's group q+1 | own q+1]
-                        const uint4 out = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-                        if (gm < m) *reinterpret_cast<uint4*>(yrow + nb + 8 * q + 8 * h) = out;
-                    }
-                }
-            } else if (gm < m) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int gn = nb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (gn < n) yrow[gn] = from_float<TY>(v[e]);
-                }
-            }
-        }
-    }
-}
-
-// ---- the 256 x 256 tile on v_mfma_f32_16x16x32 -------------------------------------------------------------------
-// Same workgroup tile, wave tile (256 rows x 32 channels), LDS image, staging and pipeline as gemm_mfma_kernel with
-// <256, 256, 1, 8>; only the matrix instruction differs.  Cycles per flop are equal, but under matrix-core load the
-// chip holds a higher clock on this shape (measured by in-process A/B on random data), so it is the one used for
-// the big tile.  Operand layout: lane (c = lane & 15, g = lane >> 4) holds 8 consecutive k of weight row c
-// (operand A) and of activation row c (operand B); D register e is channel 4 g + e, activation row c.
-// k order inside a 64-step: lane group g owns k = 16 q .. 16 q + 15 with q = {0, 3, 1, 2}[g] (one dword of packed
-// weights per 16-channel tile); MFMA group s = 0, 1 takes the dword's halfword s and the activation chunk 2 q + s.
-// That assignment of q keeps the swizzled ds_read_b128 fragment reads conflict-free: the two lane groups that share
-// an LDS cycle read chunk indices whose bits 1 and 2 have equal parity.
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef uint32_t nts_u32x4 __attribute__((ext_vector_type(4)));
-
-template <typename TX>
-__device__ __forceinline__ floatx4 mfma16(uint4 a, uint4 b, floatx4 c) {
-    if constexpr (__is_same(TX, f16)) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
-    } else {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-}
-
-// PERSIST: the grid has fewer workgroups than tiles; workgroup b walks tiles b, b + gridDim.x, ... as ONE stream of k
-// steps: the loads of the next tile's first steps are issued during the current tile's last steps and its epilogue
-// (stores are asynchronous), so the per-tile launch / prologue / drain cost is paid once per workgroup, not per tile.
-// NB = LDS tiles: 3 = a tile is requested one step (~1.3 us) before its use, enough for operands that sit in the
-// Infinity Cache; 4 = two steps ahead (the wait at mid-step leaves the newer group of loads in flight: counted vmcnt),
-// which also covers activations that come cold from HBM.
-template <typename TX, typename TY, bool HAS_BIAS, int ACT, int WAVES_M, bool PERSIST, int NB>
-__global__ void __launch_bounds__(512, 2)
-gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
-                   const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act_begin, TY* __restrict__ y,
-                   int64_t ld_y, int tiles_n, int nblk, int w_steps) {
-    constexpr int BM = 256, BN = 256, NT = 512;
-    constexpr int WAVES_N = 8 / WAVES_M;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile: 256 x 32 or 128 x 64
-    constexpr int MT = WM / 16, NTL = WN / 16;            // 16 x 16 tiles per wave: 16 x 2 or 8 x 4
-    constexpr int MH = MT / 2, NH = NTL / 2;              // per phase: MH row tiles x NTL channel tiles, NH decodes
-    constexpr int A_TILE_BYTES = BM * ROW_BYTES;
-    constexpr int ROUNDS = (BM * 8) / NT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NB * A_TILE_BYTES
-    static_assert(NB == 3 || NB == 4, "three or four activation tiles in LDS");
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int wr = wid / WAVES_N, wc = wid % WAVES_N;
-    const int q = (0x2130 >> (4 * g)) & 3;
-    const int nk = k / BK;
-    const int G = gridDim.x;
-    const int my_tiles = PERSIST ? (nblk - (int)blockIdx.x + G - 1) / G : 1;
-    const int total_steps = my_tiles * nk;
-    int vb_l = blockIdx.x, kb_l = 0;   // load cursor: tile (as a virtual block index) and k step the next loads fetch
-    int vb_c = blockIdx.x, kb_c = 0;   // the step being multiplied
-    int m0, n0;                        // origin of the tile being multiplied
-    {
-        const int tile = xcd_remap(vb_c, nblk);
-        m0 = (tile / tiles_n) * BM; n0 = (tile % tiles_n) * BN;
-    }
-
-    // Load addresses = a wave-uniform 64-bit base (tile origin + k step, kept in scalar registers) + a 32-bit per-lane byte
-    // offset inside the tile: half the address registers of 64-bit per-lane pointers and no vector address arithmetic per step.
-    const TX* a_base;
-    const uint8_t* b_base;
-    uint32_t a_off[ROUNDS], b_off[NTL];
-    auto set_load_tile = [&](int vb) __attribute__((always_inline)) {
-        const int tile = xcd_remap(vb, nblk);
-        const int lm0 = (tile / tiles_n) * BM, ln0 = (tile % tiles_n) * BN;
-        a_base = x + (int64_t)lm0 * ld_x;
-        b_base = pw + (int64_t)ln0 * ld_pw;
-#pragma unroll
-        for (int i = 0; i < ROUNDS; ++i) {
-            const int p = i * NT + tid;
-            const int row = p >> 3, cs = p & 7;
-            const int chunk = cs ^ ((row >> 1) & 7);
-            int gm = lm0 + row;
-            gm = gm < m ? gm : m - 1;
-            a_off[i] = (uint32_t)(((int64_t)(gm - lm0) * ld_x + chunk * 8) * (int64_t)sizeof(TX));
-        }
-#pragma unroll
-        for (int t = 0; t < NTL; ++t) {
-            int gn = ln0 + wc * WN + t * 16 + c;
-            gn = gn < n ? gn : n - 1;
-            b_off[t] = (uint32_t)((int64_t)(gn - ln0) * ld_pw + 4 * q);
-        }
-    };
-    set_load_tile(vb_l);
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
-    auto stage_a = [&](int kb, int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < ROUNDS; ++i) {
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + buf * A_TILE_BYTES + (i * NT + wid * 64) * 16);
-            const TX* sbase = a_base + (int64_t)kb * BK;   // wave-uniform
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(a_off[i]), "s"(dst), "s"(sbase) : "memory");
-        }
-    };
-
-    auto load_b = [&](int kb, uint32_t (&dst)[NTL]) __attribute__((always_inline)) {
-        int kw = kb;
-        kw = kw >= w_steps ? kw - w_steps : kw;
-        kw = kw >= w_steps ? kw - w_steps : kw;
-#pragma unroll
-        for (int t = 0; t < NTL; ++t)
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(dst[t]) : "v"(b_off[t]), "s"(b_base + (int64_t)kw * (BK / 4)) : "memory");
-    };
-    // fetch the cursor's step into LDS buffer `buf` / registers `w`, then advance the cursor (to the next tile of this
-    // workgroup after a tile's last step; past the very last step it stays there: harmless re-fetches into a buffer
-    // nobody reads again, so that the number of loads per step is constant)
-    auto issue_loads = [&](int buf, uint32_t (&w)[NTL]) __attribute__((always_inline)) {
-        stage_a(kb_l, buf);
-        load_b(kb_l, w);
-        if (++kb_l == nk) {
-            if (PERSIST && vb_l + G < nblk) { vb_l += G; kb_l = 0; set_load_tile(vb_l); }
-            else kb_l = nk - 1;
-        }
-    };
-    auto wait_loads = [&](uint32_t (&w)[NTL]) {
-        if constexpr (NTL == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : : "memory");
-    };
-    // as wait_loads, but the newest group of loads (one step's ROUNDS tile pieces + NTL weight dwords) stays in flight:
-    // loads complete in issue order, so at most that many outstanding means every older load has landed
-    auto wait_loads_keep_newest = [&](uint32_t (&w)[NTL]) {
-        if constexpr (NTL == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(ROUNDS + NTL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(ROUNDS + NTL) : "memory");
-    };
-
-    const int sw = (c >> 1) & 7;                 // (row >> 1) & 7 with row = 16 i + c
-    const int a_row_off = (wr * WM + c) * ROW_BYTES;
-    int a_col_off[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) a_col_off[s] = ((2 * q + s) ^ sw) * 16;
-
-    floatx4 acc[MT][NTL];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int t = 0; t < NTL; ++t) acc[i][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    const DecodeConsts dc = make_decode_consts();
-
-    auto read_a = [&](int buf, int s, int half, uint4 (&af)[MH]) __attribute__((always_inline)) {
-        const unsigned char* abase = lds + buf * A_TILE_BYTES + a_row_off + a_col_off[s] + half * MH * 16 * ROW_BYTES;
-#pragma unroll
-        for (int i = 0; i < MH; ++i) af[i] = *reinterpret_cast<const uint4*>(abase + i * 16 * ROW_BYTES);
-    };
-    auto decode_b = [&](uint32_t d, int s) { return s ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc); };
-    auto mma = [&](const uint4 (&af)[MH], int half, const uint4 (&bf)[NTL]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < MH; ++i)
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) acc[MH * half + i][t] = mfma16<TX>(bf[t], af[i], acc[MH * half + i][t]);
-    };
-    // decode NH of the NTL weight fragments of MFMA group s (the half `part`) from the packed dwords w
-    auto decode_part = [&](const uint32_t (&w)[NTL], int s, int part, uint4 (&bf)[NTL]) {
-#pragma unroll
-        for (int t = 0; t < NH; ++t) bf[part * NH + t] = decode_b(w[part * NH + t], s);
-    };
-    auto interleave_hint = [&]() {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, NH, 0);  // decode / address VALU
-        }
-    };
-
-    auto store_tile = [&]() __attribute__((always_inline)) {
-        // ---- epilogue: lane (c, g) owns activation row 16 i + c and channels 16 t + 4 g + e -------------------------------
-        // 16-bit outputs: v_permlane16_swap hands even lane groups their neighbour's 4 channels of tile 0 and odd lane
-        // groups their neighbour's 4 channels of tile 1, so every lane stores 16 contiguous bytes.
-        const float cl = fabsf(clip);
-        const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) | (uintptr_t)(ld_y * (int64_t)sizeof(TY))) & 15) == 0;
-        const int nb = n0 + wc * WN;
-        const int noff = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;   // first of the 8 channels a lane stores after the swap
-    #pragma unroll
-        for (int tp = 0; tp < NTL; tp += 2) {                  // pairs of 16-channel tiles
-            float sc[2][4], bi[2][4];
-    #pragma unroll
-            for (int t = 0; t < 2; ++t)
-    #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int gn = nb + 16 * (tp + t) + 4 * g + e;
-                    sc[t][e] = gn < n ? scale[gn] : 0.0f;
-                    bi[t][e] = (HAS_BIAS && gn < n) ? bias[gn] : 0.0f;
-                }
-    #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int gm = m0 + wr * WM + 16 * i + c;
-                float v[2][4];
-    #pragma unroll
-                for (int t = 0; t < 2; ++t)
-    #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[t][e] = epilogue_ch<HAS_BIAS, ACT>(acc[i][tp + t][e], sc[t][e], bi[t][e], cl, nb + 16 * (tp + t) + 4 * g + e, act_begin);
-                TY* yrow = y + (int64_t)(gm < m ? gm : 0) * ld_y;
-                if (vec_ok && nb + 16 * tp + 32 <= n) {
-                    if constexpr (sizeof(TY) == 4) {
-                        if (gm < m) {
-    #pragma unroll
-                            for (int t = 0; t < 2; ++t)
-                                __builtin_nontemporal_store((floatx4){v[t][0], v[t][1], v[t][2], v[t][3]}, reinterpret_cast<floatx4*>(yrow + nb + 16 * (tp + t) + 4 * g));
-                        }
-                    } else {
-                        uint2 pk[2];
-    #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            TY tmp[4];
-    #pragma unroll
-                            for (int e = 0; e < 4; ++e) tmp[e] = from_float<TY>(v[t][e]);
-                            pk[t] = *reinterpret_cast<const uint2*>(tmp);
-                        }
-                        // all 64 lanes take part in the swap (no divergence above this point)
-                        auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
-                        auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
-                        const uint4 out = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-                        // streaming (non-temporal) stores: the output is written once and is far larger than L2; +2..3 % by A/B
-                        if (gm < m) __builtin_nontemporal_store(__builtin_bit_cast(nts_u32x4, out), reinterpret_cast<nts_u32x4*>(yrow + nb + 16 * tp + noff));
-                    }
-                } else if (gm < m) {
-    #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-    #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int gn = nb + 16 * (tp + t) + 4 * g + e;
-                            if (gn < n) yrow[gn] = from_float<TY>(v[t][e]);
-                        }
-                }
-            }
-        }
-    };
-
-    uint32_t bq0[NTL], bq1[NTL], bq2[NTL], bq3[NTL];   // packed weights (16 per lane and tile) of steps NB j, NB j + 1, ...
-    uint4 afA[MH], afB[MH], bf0[NTL], bf1[NTL];   // bf0 / bf1: decoded weights of MFMA group s = 0 / 1
-    // one step = four phases (s, half of the 16 row tiles); each phase reads the NEXT phase's activation fragments
-    // first, then interleaves its 16 MFMAs with the decode of one weight fragment needed two phases later
-    // w0 / w1: weights of this step and the next; wn: the registers the loads issued in this step (for step + NB - 1) fill
-    auto step = [&](auto buf_c, uint32_t (&w0)[NTL], uint32_t (&w1)[NTL], uint32_t (&wn)[NTL]) __attribute__((always_inline)) {
-        constexpr int buf = decltype(buf_c)::value;
-        constexpr int buf1 = (buf + 1) % NB, bufn = (buf + NB - 1) % NB;
-        read_a(buf, 0, 1, afB);
-        __builtin_amdgcn_sched_barrier(0);
-        decode_part(w0, 1, 0, bf1); mma(afA, 0, bf0);
-        interleave_hint();
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(buf, 1, 0, afA);
-        __builtin_amdgcn_sched_barrier(0);
-        decode_part(w0, 1, 1, bf1); mma(afB, 1, bf0);
-        interleave_hint();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- middle of the step: tile kb+1 (and its weights w1) complete, tile kb-1 retired ----
-        if constexpr (NB == 3) wait_loads(w1);
-        else wait_loads_keep_newest(w1);
-        __builtin_amdgcn_s_barrier();
-        read_a(buf, 1, 1, afB);
-        issue_loads(bufn, wn);
-        __builtin_amdgcn_sched_barrier(0);
-        decode_part(w1, 0, 0, bf0); mma(afA, 0, bf1);
-        interleave_hint();
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(buf1, 0, 0, afA);
-        __builtin_amdgcn_sched_barrier(0);
-        decode_part(w1, 0, 1, bf0); mma(afB, 1, bf1);
-        interleave_hint();
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PERSIST) {
-            if (++kb_c == nk) {   // last step of a tile: write it out and start the next one (its first fragments are in afA / bf0)
-                store_tile();
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int t = 0; t < NTL; ++t) acc[i][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
-                kb_c = 0;
-                vb_c += G;
-                const int tile = xcd_remap(vb_c < nblk ? vb_c : nblk - 1, nblk);
-                m0 = (tile / tiles_n) * BM; n0 = (tile % tiles_n) * BN;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-
-    // prologue: NB - 1 steps requested (past the last step the cursor re-fetches it, so every count below is constant)
-    issue_loads(0, bq0);
-    issue_loads(1, bq1);
-    if constexpr (NB == 4) {
-        issue_loads(2, bq2);
-        wait_loads_keep_newest(bq0);
-        wait_loads_keep_newest(bq1);
-    } else {
-        wait_loads(bq0);
-        wait_loads(bq1);
-#pragma unroll
-        for (int t = 0; t < NTL; ++t) bq2[t] = 0;
-    }
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) bq3[t] = 0;
-    __builtin_amdgcn_s_barrier();
-    read_a(0, 0, 0, afA);
-    decode_part(bq0, 0, 0, bf0);
-    decode_part(bq0, 0, 1, bf0);
-    if constexpr (NB == 3) {
-        for (int gs = 0; gs < total_steps; gs += 3) {
-            step(std::integral_constant<int, 0>{}, bq0, bq1, bq2);
-            if (gs + 1 < total_steps) step(std::integral_constant<int, 1>{}, bq1, bq2, bq0);
-            if (gs + 2 < total_steps) step(std::integral_constant<int, 2>{}, bq2, bq0, bq1);
-        }
-    } else {
-        for (int gs = 0; gs < total_steps; gs += 4) {
-            step(std::integral_constant<int, 0>{}, bq0, bq1, bq3);
-            if (gs + 1 < total_steps) step(std::integral_constant<int, 1>{}, bq1, bq2, bq0);
-            if (gs + 2 < total_steps) step(std::integral_constant<int, 2>{}, bq2, bq3, bq1);
-            if (gs + 3 < total_steps) step(std::integral_constant<int, 3>{}, bq3, bq0, bq2);
-        }
-    }
-    wait_loads(bq0);
-    wait_loads(bq1);
-    wait_loads(bq2);
-    wait_loads(bq3);
-    if constexpr (!PERSIST) store_tile();
-}
-
 // Sum the split-K slabs in a fixed order (deterministic: slab 0, 1, 2, ...) and apply the fused epilogue.
-// One thread per output element; the slab loads of 8 consecutive splits are issued together (they are
-// independent; a one-load-at-a-time loop would pay the memory latency `splits` times).
-template <typename TY, bool HAS_BIAS, int ACT>
+// VEC = 4: one thread per four consecutive outputs of a row (16-byte slab loads, n % 4 == 0); the loads of up to 8 splits are
+// issued together (they are independent; a one-load-at-a-time loop would pay the memory latency `splits` times).
+template <typename TY, bool HAS_BIAS, int ACT, int VEC>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t m, int64_t n,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
                                                             float clip, int act_begin, TY* __restrict__ y, int64_t ld_y) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
     const float c = fabsf(clip);
-    const int64_t total = m * n, stride = m * n;
+    const int64_t per_row = n / VEC, total = m * per_row, stride = m * n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / n, col = i - r * n;
-        const float* p = slab + i;
-        float acc = 0.0f;
-        int s = 0;
+        const int64_t r = i / per_row, col = (i - r * per_row) * VEC;
+        const float* p = slab + r * n + col;
+        vec_t acc = *reinterpret_cast<const vec_t*>(p);   // slab 0 first: the sum is s0 + s1 + s2 + ...
+        int s = 1;
         for (; s + 8 <= splits; s += 8) {
-            float v[8];
+            vec_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(s + u) * stride];
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vec_t*>(p + (int64_t)(s + u) * stride);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += v[u];
         }
-        for (; s < splits; ++s) acc += p[(int64_t)s * stride];
-        y[r * ld_y + col] = from_float<TY>(epilogue_ch<HAS_BIAS, ACT>(acc, scale[col], HAS_BIAS ? bias[col] : 0.0f, c, (int)col, act_begin));
+        if (s + 4 <= splits) {
+            vec_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const vec_t*>(p + (int64_t)(s + u) * stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u];
+            s += 4;
+        }
+        for (; s < splits; ++s) acc += *reinterpret_cast<const vec_t*>(p + (int64_t)s * stride);
+        TY out[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float a = acc[e];
+            out[e] = from_float<TY>(epilogue_ch<HAS_BIAS, ACT>(a, scale[col + e], HAS_BIAS ? bias[col + e] : 0.0f, c, (int)(col + e), act_begin));
+        }
+        TY* dst = y + r * ld_y + col;
+        if constexpr (VEC == 4) {
+            if constexpr (sizeof(TY) == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(out);
+            else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(out);
+        } else {
+            dst[0] = out[0];
+        }
     }
 }
 
 template <typename TY>
 static int launch_reduce(const float* slab, int splits, int64_t m, int64_t n, const float* scale, const float* bias, float clip,
                          int act, int act_begin, TY* y, int64_t ld_y, hipStream_t st) {
-    int64_t g = ceil_div(m * n, 256);
-    g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    // four outputs per thread when rows of the slabs and of y can be moved 16 / 8 bytes at a time
+    const bool vec = n % 4 == 0 && aligned(slab, 16) && aligned(y, 4 * sizeof(TY)) && (ld_y * sizeof(TY)) % (4 * sizeof(TY)) == 0;
+    int64_t g = ceil_div(vec ? m * (n / 4) : m * n, 256);
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
     const dim3 grid((unsigned)g), block(256);
-#define TVL_RD(HB, ACT) hipLaunchKernelGGL((splitk_reduce_kernel<TY, HB, ACT>), grid, block, 0, st, slab, splits, m, n, scale, bias, clip, act_begin, y, ld_y)
+#define TVL_RD(HB, ACT)                                                                                                                    \
+    do {                                                                                                                                   \
+        if (vec) hipLaunchKernelGGL((splitk_reduce_kernel<TY, HB, ACT, 4>), grid, block, 0, st, slab, splits, m, n, scale, bias, clip, act_begin, y, ld_y); \
+        else hipLaunchKernelGGL((splitk_reduce_kernel<TY, HB, ACT, 1>), grid, block, 0, st, slab, splits, m, n, scale, bias, clip, act_begin, y, ld_y);     \
+    } while (0)
     if (bias) {
         if (act == TVL_ACT_GELU_TANH) TVL_RD(true, TVL_ACT_GELU_TANH); else TVL_RD(true, TVL_ACT_NONE);
     } else {
@@ -756,8 +118,7 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
         const int steps_per_split = (int)ceil_div(total_steps, splits);
         splits = (int)ceil_div(total_steps, steps_per_split);  // no empty split
         auto kern = gemm_mfma_kernel<TX, float, BM, BN, WAVES_M, WAVES_N, false, TVL_ACT_NONE, true>;
-        if (lds_bytes > 48 * 1024)
-            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (int rc = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc != TVL_OK) return rc;
         hipLaunchKernelGGL(kern, dim3(nblk, splits), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip,
                            0, slab, n, tiles_n, nblk, steps_per_split, w_steps);
         TVL_LAUNCH_CHECK();
@@ -768,18 +129,18 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
     do {                                                                                                           \
         if constexpr (BM == 256) {   /* the big tile runs on the 16x16x32 instruction */                            \
             /* 1 x 8 waves; the 2 x 4 layout (WAVES_M = 2: half the LDS reads, twice the weight decode) measured 21 % slower */ \
-            const bool persist = nblk > NUM_CUS;   /* more tiles than CUs: one workgroup per CU walks several (+2..7 %) */ \
+            const int cus = device_cu_count();                                                                      \
+            const bool persist = nblk > cus;   /* more tiles than CUs: one workgroup per CU walks several (+2..7 %) */ \
             /* the persistent form has no registers left for the fourth weight set (it would spill): three tiles there */ \
             auto k16 = persist ? gemm_mfma16_kernel<TX, TY, HB, ACT, 1, true, NBUF> : gemm_mfma16_kernel<TX, TY, HB, ACT, 1, false, BIG_NB>; \
             const size_t lds16 = (size_t)(persist ? NBUF : BIG_NB) * BM * ROW_BYTES;                                \
-            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16)); \
-            hipLaunchKernelGGL(k16, dim3(persist ? NUM_CUS : nblk), block, lds16, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, \
-                               bias, clip, act_begin, y, ld_y, tiles_n, nblk, w_steps);                            \
+            if (int rc = set_dynamic_lds_limit((const void*)k16, lds16); rc != TVL_OK) return rc;                   \
+            hipLaunchKernelGGL(k16, dim3(persist ? cus : nblk), block, lds16, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, \
+                               bias, clip, act_begin, y, ld_y, tiles_n, nblk, w_steps, 0);                         \
             break;                                                                                                 \
         }                                                                                                          \
         auto kern = gemm_mfma_kernel<TX, TY, BM, BN, WAVES_M, WAVES_N, HB, ACT, false>;                             \
-        if (lds_bytes > 48 * 1024)                                                                                 \
-            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        if (int rc = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc != TVL_OK) return rc;                 \
         hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act_begin, \
                            y, ld_y, tiles_n, nblk, 0, w_steps);                                                    \
     } while (0)
@@ -800,30 +161,62 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
 // Split-K adds one more launch plus writing and re-reading the float32 slabs (~8 TB/s: they mostly stay in the
 // Infinity Cache): it fills the chip when
 // the output has few tiles, and the slab term stops it where the partial sums would cost more than idle CUs.
-struct GemmPlan { int bm, bn, splits; };
-struct TileCost { int bm, bn, occupancy; double fixed_us, step_alone_us, step_shared_us; };
+// kind: KIND_BIG = the 256 x 256 tile, KIND_MID = 128-row tiles of the same 16x16x32 kernel (gemm_mid.hip), KIND_SMALL = the
+// 32x32x16 kernel's 64- and 32-row tiles (few rows per tile: a decoded weight feeds only one or two row tiles there)
+enum { KIND_SMALL = 0, KIND_MID = 1, KIND_BIG = 2 };
+struct GemmPlan { int kind, bm, bn, splits; };
+// step_light: time per k step of a workgroup alone on its CU while at most ~60 % of the CUs are busy; step_full: the same
+// with every CU busy (the shared L2 / fabric path slows the tile loads down); step_shared: per workgroup-step when two or more
+// share a CU.  Measured with TVL_FORCE_PLAN over M = 256 .. 4096 at N = K = 4096 and the moondream prefill shapes.
+struct TileCost { int kind, bm, bn, occupancy; double fixed_us, step_light_us, step_full_us, step_shared_us; };
 static const TileCost TILE_COSTS[] = {
-    {256, 256, 1, 14.0, 1.57, 1.57},   // 8 waves, 96 KiB LDS
-    {128, 128, 2, 5.0, 0.70, 0.53},    // 4 waves, 48 KiB LDS
-    {64, 128, 2, 4.5, 0.45, 0.39},
-    {32, 128, 3, 4.0, 0.21, 0.21},
+    {KIND_BIG, 256, 256, 1, 14.0, 1.20, 1.57, 1.57},    // 8 waves, 96 / 128 KiB LDS
+    {KIND_MID, 128, 256, 1, 7.0, 0.62, 0.84, 0.84},     // 8 waves, 64 KiB LDS
+    {KIND_MID, 128, 128, 2, 6.0, 0.42, 0.47, 0.44},     // 4 waves, 64 KiB LDS
+    {KIND_SMALL, 64, 128, 2, 4.5, 0.45, 0.45, 0.39},
+    {KIND_SMALL, 32, 128, 3, 4.0, 0.21, 0.21, 0.21},
 };
+
+// TVL_FORCE_PLAN="kind:bm:bn:splits" pins the choice (tuning and tests: every tile can be timed on every shape); read once.
+static bool forced_plan(GemmPlan* p) {
+    static const GemmPlan forced = [] {
+        GemmPlan f{-1, 0, 0, 0};
+        if (const char* e = getenv("TVL_FORCE_PLAN")) {
+            if (sscanf(e, "%d:%d:%d:%d", &f.kind, &f.bm, &f.bn, &f.splits) != 4) f.kind = -1;
+        }
+        return f;
+    }();
+    if (forced.kind < 0) return false;
+    *p = forced;
+    return true;
+}
+
 static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_bytes) {
     const int64_t steps = k / BK;
     const int64_t max_by_ws = (int64_t)(workspace_bytes / ((size_t)m * n * sizeof(float)));
-    GemmPlan best{128, 128, 1};
+    GemmPlan best{KIND_MID, 128, 128, 1};
+    if (forced_plan(&best)) {
+        if (best.splits > max_by_ws) best.splits = max_by_ws > 1 ? (int)max_by_ws : 1;
+        if (best.splits > steps) best.splits = (int)steps;
+        return best;
+    }
+    const int cus = device_cu_count();
     double best_t = 1e30;
     for (const TileCost& tc : TILE_COSTS) {
         if (tc.bm > 32 && m <= tc.bm / 2) continue;   // more than half of the tile's rows would be padding
+        if (tc.kind == KIND_SMALL && m > 3 * tc.bm / 2) continue;   // few rows per decoded weight: only where the 128-row tiles would be mostly padding
         const int64_t tiles = ceil_div(m, tc.bm) * ceil_div(n, tc.bn);
         for (int64_t s = 1; s <= 64; ++s) {
-            if (s > 1 && (s > max_by_ws || steps / s < 2 || tc.bm == 256)) break;
+            if (s > 1 && (s > max_by_ws || steps / s < 2 || tc.kind == KIND_BIG)) break;
             const int64_t per = ceil_div(steps, s);
-            const int64_t q = ceil_div(tiles * s, 256);
+            const int64_t q = ceil_div(tiles * s, cus);
+            const double load = (double)(tiles * s) / (double)cus;
             double t = (double)ceil_div(q, tc.occupancy) * tc.fixed_us +
-                       (double)per * (q == 1 ? tc.step_alone_us : (double)q * tc.step_shared_us);
-            if (s > 1) t += 2.5 + 2.0 * (double)s * (double)m * (double)n * 4.0 / 8.0e6;
-            if (t < best_t) { best_t = t; best = GemmPlan{tc.bm, tc.bn, (int)s}; }
+                       (double)per * (q == 1 ? (load <= 0.6 ? tc.step_light_us : tc.step_full_us) : (double)q * tc.step_shared_us);
+            // the 256 x 256 tile walks its q tiles per CU as one stream of k steps: the fixed cost once, ~4 us of epilogue per tile
+            if (tc.kind == KIND_BIG && q > 1) t = tc.fixed_us + (double)q * ((double)per * tc.step_full_us + 4.0);
+            if (s > 1) t += 3.0 + 3.0 * (double)s * (double)m * (double)n * 4.0 / 8.0e6;
+            if (t < best_t) { best_t = t; best = GemmPlan{tc.kind, tc.bm, tc.bn, (int)s}; }
         }
     }
     return best;
@@ -837,9 +230,13 @@ static int launch_mfma_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const
     const bool ws_ok = workspace != nullptr && aligned(workspace, 16);
     const GemmPlan p = plan_gemm(m, n, k, ws_ok ? workspace_bytes : 0);
     float* slab = (float*)workspace;
-    if (p.bm == 256)
+    if (p.kind == KIND_BIG)
         return launch_cfg<TX, TY, 256, 256, 1, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, 1, slab, w_steps, st);
-    if (p.bm == 128)
+    if (p.kind == KIND_MID)
+        return launch_gemm_mid(x, std::is_same<TX, f16>::value ? TVL_F16 : TVL_BF16, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y,
+                               std::is_same<TY, float>::value ? TVL_F32 : (std::is_same<TY, f16>::value ? TVL_F16 : TVL_BF16), ld_y, p.bm, p.bn,
+                               p.splits, slab, w_steps, st);
+    if (p.bm == 128)   // (only by TVL_FORCE_PLAN: the 32x32x16 kernel's 128 x 128 tile, superseded by the mid-size kernel)
         return launch_cfg<TX, TY, 128, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, slab, w_steps, st);
     if (p.bm == 64)
         return launch_cfg<TX, TY, 64, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, slab, w_steps, st);

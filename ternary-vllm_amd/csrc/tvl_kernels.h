@@ -38,6 +38,15 @@ size_t gemm_mfma_workspace_bytes(int x_dtype, int64_t m, int64_t n, int64_t k);
 int launch_splitk_reduce(const float* slab, int splits, int64_t m, int64_t n, const float* scale, const float* bias, float clip,
                          int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
 
+// gemm_mid.hip: 128-row tiles of the 16x16x32 kernel (with or without split-K into float32 slabs at `slab`)
+int launch_gemm_mid(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                    const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y,
+                    int bm, int bn, int splits, float* slab, int w_steps, hipStream_t st);
+
+// device_info.hip: per-device facts looked up once
+int device_cu_count();                                            // compute units of the current device (256 on MI355X)
+int set_dynamic_lds_limit(const void* kernel, size_t lds_bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize), once per kernel and device
+
 // gemm_skinny.hip
 bool gemm_skinny_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw);
 int launch_gemm_skinny(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
