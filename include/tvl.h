@@ -64,6 +64,19 @@ const char* tvl_build_info(void);
 int tvl_quantize_pack(const void* w, int w_dtype, int64_t n, int64_t k, int64_t ld_w, int mode,
                       float threshold, uint8_t* pw, int64_t ld_pw, void* stream);
 
+/* tvl_quantize_pack for `count` matrices in as few launches as possible (a converted checkpoint: every selected layer of a
+ * model into one packed arena - the loop of transfer_dense_params_torch_to_tf calls at utils/conversion.py:126-137, one
+ * `ternary_act -> int8 -> ops.pack_fn` per Dense, :71-72).  `items` is a HOST array, read before the call returns; the
+ * pointers inside it are device pointers; ld = 0 means dense; all matrices share w_dtype, mode and threshold.  Same bytes
+ * as `count` single calls. */
+typedef struct tvl_pack_item {
+    const void* w;   /* latent weights [n, ld_w] */
+    int64_t n, k, ld_w;
+    uint8_t* pw;     /* packed rows [n, ld_pw] */
+    int64_t ld_pw;
+} tvl_pack_item;
+int tvl_quantize_pack_batch(const tvl_pack_item* items, int64_t count, int w_dtype, int mode, float threshold, void* stream);
+
 /* Pack already-quantized int8 values in {-1,0,+1} (code = value + 1, low two bits).
  * Replaces `ops.pack_fn(int8 [N,K])` (utils/conversion.py:72) / ScaledTernaryPackedMM.pack_fn
  * (impl/tf/moondream/ternary.py:374-398). */

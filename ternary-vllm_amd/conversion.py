@@ -121,15 +121,20 @@ class PackedArena:
         packed = torch.full((off,), 0x55, dtype=torch.uint8, device=device)  # pad bytes = four zeros
         scales = torch.empty((voff,), dtype=torch.float32, device=device)
         biases = torch.zeros((voff,), dtype=torch.float32, device=device)
+        pending = {}   # quantization -> (latent weights, arena views): packed together, one launch per 32 layers
         for e in entries:
             w, scale, bias = fetch(e.name)
             if tuple(w.shape) != (e.n, e.k) or scale.numel() != e.n or (bias is not None and bias.numel() != e.n):
                 raise ValueError(f"layer {e.name}: weights {tuple(w.shape)}, scale {tuple(scale.shape)} do not match [{e.n}, {e.k}]")
             view = packed[e.offset:e.offset + e.n * e.ld].view(e.n, e.ld)
-            ops.ternarize_pack(w.to(device), 0.5, e.quantization, out=view)
+            ws, views = pending.setdefault((e.quantization, w.dtype), ([], []))
+            ws.append(w.to(device))
+            views.append(view)
             scales[e.vec_offset:e.vec_offset + e.n] = scale.to(device, torch.float32).reshape(-1)
             if bias is not None:
                 biases[e.vec_offset:e.vec_offset + e.n] = bias.to(device, torch.float32).reshape(-1)
+        for (quant, _), (ws, views) in pending.items():
+            ops.ternarize_pack_batch(ws, 0.5, quant, outs=views)
         return cls(packed, scales, biases, entries)
 
     @classmethod

@@ -52,6 +52,33 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
 //   quad_or gathers bytes 4q..4q+3 of load i into dword 16 i + q (held by the 4 lanes of quad q)
 //   lane l stores dword 16 (l & 3) + (l >> 2)
 // Requires k % 16 == 0, 16-byte aligned rows of w, 4-byte aligned rows of pw.
+// One wave, one chunk: 1024 consecutive weights of a row, starting at weight kc (src points at them) -> 256 packed bytes of that row.
+template <typename T, int MODE>
+__device__ __forceinline__ void pack_chunk(const T* __restrict__ src, int64_t kc, int64_t k, float thr, uint8_t* __restrict__ pw_row, int lane) {
+    float v[4][4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t e = (int64_t)(64 * i + lane) * 4;
+        ok[i] = (kc + e) < k;
+        if (ok[i]) load4<T>(src + e, v[i]);
+    }
+    uint32_t d[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t b = 0;
+        if (ok[i]) {
+            b = quantize_code<MODE>(v[i][0], thr) | (quantize_code<MODE>(v[i][1], thr) << 2) |
+                (quantize_code<MODE>(v[i][2], thr) << 4) | (quantize_code<MODE>(v[i][3], thr) << 6);
+        }
+        d[i] = quad_or(b << (8 * (lane & 3)));
+    }
+    const int sel = lane & 3;
+    const uint32_t mine = sel == 0 ? d[0] : sel == 1 ? d[1] : sel == 2 ? d[2] : d[3];
+    const int64_t dw = kc / 16 + 16 * sel + (lane >> 2);
+    if (dw < k / 16) *reinterpret_cast<uint32_t*>(pw_row + dw * 4) = mine;
+}
+
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) quantize_pack_fast_kernel(const T* __restrict__ w, int64_t n, int64_t k,
                                                                  int64_t ld_w, float thr, uint8_t* __restrict__ pw,
@@ -61,33 +88,39 @@ __global__ void __launch_bounds__(256) quantize_pack_fast_kernel(const T* __rest
     const int64_t total = n * chunks_per_row;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const int64_t dwords_per_row = k / 16;
     for (int64_t c = wave0; c < total; c += nwaves) {
         const int64_t row = c / chunks_per_row;
         const int64_t kc = (c - row * chunks_per_row) * 1024;  // first weight of the chunk
-        const T* src = w + row * ld_w + kc;
-        float v[4][4];
-        bool ok[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t e = (int64_t)(64 * i + lane) * 4;
-            ok[i] = (kc + e) < k;
-            if (ok[i]) load4<T>(src + e, v[i]);
+        pack_chunk<T, MODE>(w + row * ld_w + kc, kc, k, thr, pw + row * ld_pw, lane);
+    }
+}
+
+// Several matrices in ONE launch (a converted checkpoint: every layer of the packed arena).  The descriptors travel by value in
+// the kernel arguments; a wave finds the matrix of its chunk by bisection over the chunk prefix sums.
+constexpr int PACK_BATCH_MAX = 32;
+struct PackBatch {
+    const void* w[PACK_BATCH_MAX];
+    uint8_t* pw[PACK_BATCH_MAX];
+    int64_t k[PACK_BATCH_MAX], ld_w[PACK_BATCH_MAX], ld_pw[PACK_BATCH_MAX];
+    int64_t chunk_begin[PACK_BATCH_MAX + 1];   // prefix sums of n * ceil(k / 1024)
+    int count;
+};
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) quantize_pack_batch_kernel(const PackBatch b, float thr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t total = b.chunk_begin[b.count];
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t c = wave0; c < total; c += nwaves) {
+        int lo = 0, hi = b.count;          // chunk_begin[lo] <= c < chunk_begin[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (c >= b.chunk_begin[mid]) lo = mid; else hi = mid;
         }
-        uint32_t d[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t b = 0;
-            if (ok[i]) {
-                b = quantize_code<MODE>(v[i][0], thr) | (quantize_code<MODE>(v[i][1], thr) << 2) |
-                    (quantize_code<MODE>(v[i][2], thr) << 4) | (quantize_code<MODE>(v[i][3], thr) << 6);
-            }
-            d[i] = quad_or(b << (8 * (lane & 3)));
-        }
-        const int sel = lane & 3;
-        const uint32_t mine = sel == 0 ? d[0] : sel == 1 ? d[1] : sel == 2 ? d[2] : d[3];
-        const int64_t dw = kc / 16 + 16 * sel + (lane >> 2);
-        if (dw < dwords_per_row) *reinterpret_cast<uint32_t*>(pw + row * ld_pw + dw * 4) = mine;
+        const int64_t k = b.k[lo], chunks_per_row = (k + 1023) / 1024, lc = c - b.chunk_begin[lo];
+        const int64_t row = lc / chunks_per_row;
+        const int64_t kc = (lc - row * chunks_per_row) * 1024;
+        pack_chunk<T, MODE>(static_cast<const T*>(b.w[lo]) + row * b.ld_w[lo] + kc, kc, k, thr, b.pw[lo] + row * b.ld_pw[lo], lane);
     }
 }
 
@@ -335,6 +368,61 @@ static int launch_quantize_pack_t(const T* w, int64_t n, int64_t k, int64_t ld_w
 #undef TVL_QP
     TVL_LAUNCH_CHECK();
     return TVL_OK;
+}
+
+template <typename T>
+static int launch_pack_batch_t(const PackBatch& b, int mode, float thr, hipStream_t st) {
+    const unsigned grid = grid_for(b.chunk_begin[b.count], 4);
+    switch (mode) {
+        case TVL_Q_TERNARY: hipLaunchKernelGGL((quantize_pack_batch_kernel<T, TVL_Q_TERNARY>), dim3(grid), dim3(256), 0, st, b, thr); break;
+        case TVL_Q_SIGN: hipLaunchKernelGGL((quantize_pack_batch_kernel<T, TVL_Q_SIGN>), dim3(grid), dim3(256), 0, st, b, thr); break;
+        case TVL_Q_STEP: hipLaunchKernelGGL((quantize_pack_batch_kernel<T, TVL_Q_STEP>), dim3(grid), dim3(256), 0, st, b, thr); break;
+        default: set_error("unknown quantizer mode %d", mode); return TVL_ERR_INVALID;
+    }
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+int launch_quantize_pack(const void* w, int w_dtype, int64_t n, int64_t k, int64_t ld_w, int mode, float thr, uint8_t* pw, int64_t ld_pw,
+                         hipStream_t st);
+
+// items: HOST array.  Matrices the fast kernel can take (k % 16 == 0, 16-byte loadable rows, dword-storable packed rows) go out in
+// launches of up to PACK_BATCH_MAX matrices each; the others one by one through the single-matrix path.
+int launch_quantize_pack_batch(const tvl_pack_item* items, int64_t count, int w_dtype, int mode, float thr, hipStream_t st) {
+    const size_t es = dtype_size(w_dtype);
+    PackBatch b;
+    b.count = 0;
+    b.chunk_begin[0] = 0;
+    auto flush = [&]() -> int {
+        if (b.count == 0) return TVL_OK;
+        int rc;
+        switch (w_dtype) {
+            case TVL_F32: rc = launch_pack_batch_t<float>(b, mode, thr, st); break;
+            case TVL_F16: rc = launch_pack_batch_t<f16>(b, mode, thr, st); break;
+            default: rc = launch_pack_batch_t<bf16_t>(b, mode, thr, st); break;
+        }
+        b.count = 0;
+        return rc;
+    };
+    for (int64_t i = 0; i < count; ++i) {
+        const tvl_pack_item& it = items[i];
+        if (it.n == 0 || it.k == 0) continue;
+        const int64_t ld_w = it.ld_w ? it.ld_w : it.k, ld_pw = it.ld_pw ? it.ld_pw : ceil_div(it.k, 4);
+        const bool fast = (it.k % 16 == 0) && aligned(it.w, 4 * es) && (ld_w % 4 == 0) && aligned(it.pw, 4) && (ld_pw % 4 == 0);
+        if (!fast) {
+            const int rc = launch_quantize_pack(it.w, w_dtype, it.n, it.k, ld_w, mode, thr, it.pw, ld_pw, st);
+            if (rc != TVL_OK) return rc;
+            continue;
+        }
+        const int j = b.count;
+        b.w[j] = it.w; b.pw[j] = it.pw; b.k[j] = it.k; b.ld_w[j] = ld_w; b.ld_pw[j] = ld_pw;
+        b.chunk_begin[j + 1] = b.chunk_begin[j] + it.n * ceil_div(it.k, 1024);
+        if (++b.count == PACK_BATCH_MAX) {
+            const int rc = flush();
+            if (rc != TVL_OK) return rc;
+        }
+    }
+    return flush();
 }
 
 int launch_quantize_pack(const void* w, int w_dtype, int64_t n, int64_t k, int64_t ld_w, int mode, float thr, uint8_t* pw,

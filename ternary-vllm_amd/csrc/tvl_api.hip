@@ -51,6 +51,25 @@ int tvl_quantize_pack(const void* w, int w_dtype, int64_t n, int64_t k, int64_t 
     return launch_quantize_pack(w, w_dtype, n, k, ld_w, mode, threshold, pw, ld_pw, (hipStream_t)stream);
 }
 
+int tvl_quantize_pack_batch(const tvl_pack_item* items, int64_t count, int w_dtype, int mode, float threshold, void* stream) {
+    TVL_REQUIRE(count >= 0, "quantize_pack_batch: negative count");
+    TVL_REQUIRE(float_dtype(w_dtype), "quantize_pack_batch: weight dtype must be f32/f16/bf16, got %d", w_dtype);
+    TVL_REQUIRE(mode == TVL_Q_TERNARY || mode == TVL_Q_SIGN || mode == TVL_Q_STEP, "quantize_pack_batch: unknown quantizer %d", mode);
+    if (count == 0) return TVL_OK;
+    TVL_REQUIRE(items != nullptr, "quantize_pack_batch: NULL item array");
+    for (int64_t i = 0; i < count; ++i) {
+        const tvl_pack_item& it = items[i];
+        TVL_REQUIRE(it.n >= 0 && it.k >= 0, "quantize_pack_batch: item %lld has a negative shape", (long long)i);
+        TVL_REQUIRE(it.ld_w == 0 || it.ld_w >= it.k, "quantize_pack_batch: item %lld: ld_w=%lld < k=%lld", (long long)i, (long long)it.ld_w, (long long)it.k);
+        TVL_REQUIRE(it.ld_pw == 0 || it.ld_pw >= ceil_div(it.k, 4), "quantize_pack_batch: item %lld: ld_pw=%lld < ceil(k/4)=%lld", (long long)i,
+                    (long long)it.ld_pw, (long long)ceil_div(it.k, 4));
+        if (it.n == 0 || it.k == 0) continue;
+        TVL_REQUIRE(it.w && it.pw, "quantize_pack_batch: item %lld has a NULL pointer", (long long)i);
+        TVL_REQUIRE(aligned(it.w, dtype_size(w_dtype)), "quantize_pack_batch: item %lld: misaligned weight pointer", (long long)i);
+    }
+    return launch_quantize_pack_batch(items, count, w_dtype, mode, threshold, (hipStream_t)stream);
+}
+
 int tvl_pack_i8(const int8_t* t, int64_t n, int64_t k, int64_t ld_t, uint8_t* pw, int64_t ld_pw, void* stream) {
     TVL_REQUIRE(n >= 0 && k >= 0, "pack: negative shape");
     if (ld_t == 0) ld_t = k;
@@ -136,6 +155,8 @@ size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k) { ret
 static int dispatch_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
                            const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y,
                            void* workspace, size_t workspace_bytes, hipStream_t st, bool allow_pad) {
+    if (gemm_rows_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
+        return launch_gemm_rows(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
     if (gemv_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
         return launch_gemv(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
     if (gemm_stream_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))

@@ -5,11 +5,14 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include "../../include/tvl.h"
+
 namespace tvl {
 
 // pack_kernels.hip
 int launch_quantize_pack(const void* w, int w_dtype, int64_t n, int64_t k, int64_t ld_w, int mode, float thr, uint8_t* pw,
                          int64_t ld_pw, hipStream_t st);
+int launch_quantize_pack_batch(const tvl_pack_item* items, int64_t count, int w_dtype, int mode, float thr, hipStream_t st);
 int launch_pack_i8(const int8_t* t, int64_t n, int64_t k, int64_t ld_t, uint8_t* pw, int64_t ld_pw, hipStream_t st);
 int launch_unpack(const uint8_t* pw, int64_t n, int64_t k, int64_t ld_pw, void* out, int out_dtype, int64_t ld_out, hipStream_t st);
 int launch_pack_planar(const int8_t* t, int64_t len, int format, uint8_t* pw, hipStream_t st);
@@ -46,6 +49,11 @@ int launch_gemm_mid(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld
 // device_info.hip: per-device facts looked up once
 int device_cu_count();                                            // compute units of the current device (256 on MI355X)
 int set_dynamic_lds_limit(const void* kernel, size_t lds_bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize), once per kernel and device
+
+// gemm_rows.hip: few activation rows (3 .. 32 on layers where it wins), one launch, no workspace
+bool gemm_rows_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw);
+int launch_gemm_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                     const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
 
 // gemm_skinny.hip
 bool gemm_skinny_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw);

@@ -39,6 +39,7 @@ SIGNATURES = {
     "tvl_last_error": (ctypes.c_char_p, []),
     "tvl_build_info": (ctypes.c_char_p, []),
     "tvl_quantize_pack": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_int, _c_f32, _c_vp, _c_i64, _c_vp]),
+    "tvl_quantize_pack_batch": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_f32, _c_vp]),
     "tvl_pack_i8": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_vp]),
     "tvl_unpack": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_int, _c_i64, _c_vp]),
     "tvl_pack_planar_i8": (_c_int, [_c_vp, _c_i64, _c_int, _c_vp, _c_vp]),
@@ -245,6 +246,37 @@ def ternarize_pack(w: torch.Tensor, threshold: float = 0.5, quantization: str = 
         _check(_lib.tvl_quantize_pack(w.data_ptr(), _dt(w, "ternarize_pack"), n, k, _ld(w), _QUANT[quantization],
                                       float(threshold), out.data_ptr(), _ld(out), _stream(w)))
     return out
+
+
+class _PackItem(ctypes.Structure):   # tvl_pack_item of include/tvl.h
+    _fields_ = [("w", _c_vp), ("n", _c_i64), ("k", _c_i64), ("ld_w", _c_i64), ("pw", _c_vp), ("ld_pw", _c_i64)]
+
+
+def ternarize_pack_batch(ws, threshold: float = 0.5, quantization: str = "ternary", outs=None):
+    """:func:`ternarize_pack` for a list of latent weight matrices (same dtype, same device) in as few launches as
+    possible - every layer of a checkpoint into its place in a packed arena (``utils/conversion.py:126-137`` calls the
+    per-layer transfer in a loop).  ``outs``: optional list of uint8 ``[N_i, >= ceil(K_i / 4)]`` destinations (views into an
+    arena); returns the list of packed tensors."""
+    if quantization not in _QUANT:
+        raise ValueError(f"Unknown quantization: {quantization}")
+    ws = [_rows(_gpu(w, "ternarize_pack_batch").detach(), "ternarize_pack_batch") for w in ws]
+    if not ws:
+        return []
+    dev, dt = ws[0].device, ws[0].dtype
+    if any(w.device != dev or w.dtype != dt for w in ws):
+        raise ValueError("ternarize_pack_batch: all matrices must share one device and one dtype")
+    if outs is None:
+        outs = [torch.empty((w.shape[0], packed_row_bytes(w.shape[1])), dtype=torch.uint8, device=dev) for w in ws]
+    if len(outs) != len(ws):
+        raise ValueError("ternarize_pack_batch: `outs` must have one entry per matrix")
+    outs = [_check_pw(o, w.shape[0], w.shape[1], "ternarize_pack_batch(out)") for o, w in zip(outs, ws)]
+    items = (_PackItem * len(ws))()
+    for it, w, o in zip(items, ws, outs):
+        it.w, it.n, it.k, it.ld_w, it.pw, it.ld_pw = w.data_ptr(), w.shape[0], w.shape[1], _ld(w), o.data_ptr(), _ld(o)
+    with torch.cuda.device(dev):
+        _check(_lib.tvl_quantize_pack_batch(ctypes.cast(items, _c_vp), len(ws), _dt(ws[0], "ternarize_pack_batch"), _QUANT[quantization],
+                                            float(threshold), _stream(ws[0])))
+    return outs
 
 
 def quantize(w: torch.Tensor, quantization: str = "ternary", threshold: float = 0.5,

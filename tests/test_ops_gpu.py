@@ -168,6 +168,48 @@ def test_ternarize_pack_threshold_and_strides(ops, dev):
     assert ops.ternarize_pack(w).cpu().tolist() == [[0b10001001]]  # nan -> 0, +inf -> +1, -inf -> -1, 0.5 -> +1
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_ternarize_pack_batch_matches_single_calls_and_oracle(ops, dev, dtype):
+    """Many matrices in one launch (a checkpoint's layers into an arena): the bytes of the single-matrix calls and of the oracle.
+    40 matrices cross the 32-per-launch limit; odd k, a misaligned view and an empty matrix take the per-matrix path; the
+    destinations are row-padded views into one buffer whose pad bytes must stay untouched."""
+    rng = np.random.default_rng(17)
+    shapes = [(int(rng.integers(1, 70)), 16 * int(rng.integers(1, 200))) for _ in range(36)] + [(5, 1030), (3, 7), (0, 64), (4, 2048)]
+    ws, outs, views, want = [], [], [], []
+    arena = torch.full((sum(n * (-(-((k + 3) // 4) // 16) * 16) for n, k in shapes) + 64,), 0xEE, dtype=torch.uint8, device=dev)
+    off = 0
+    for i, (n, k) in enumerate(shapes):
+        w = rng.uniform(-1, 1, size=(n, k)).astype(np.float32)
+        if w.size >= 4:
+            w.reshape(-1)[:4] = [0.5, -0.5, 0.4999, -0.4999]
+        wt = torch.from_numpy(w).to(dev).to(dtype)
+        if i == 7:                                       # a view that starts 1 element into a wider buffer: not 16-byte loadable
+            wide = torch.zeros((n, k + 8), dtype=dtype, device=dev)
+            wide[:, 1:1 + k] = wt
+            wt = wide[:, 1:1 + k]
+        ld = -(-((k + 3) // 4) // 16) * 16
+        view = arena[off:off + n * ld].view(n, ld)
+        off += n * ld
+        ws.append(wt); views.append(view)
+        want.append(O.pack_format_c(O.ternarize(wt.float().cpu().numpy())) if n else np.zeros((0, (k + 3) // 4), np.uint8))
+    got = ops.ternarize_pack_batch(ws, 0.5, "ternary", outs=views)
+    for (n, k), g, v, w_, wt in zip(shapes, got, views, want, ws):
+        kb = (k + 3) // 4
+        assert np.array_equal(v.cpu().numpy()[:, :kb], w_), (n, k)
+        assert torch.all(v[:, kb:] == 0xEE)                                      # row padding untouched
+        if n:
+            assert torch.equal(v[:, :kb], ops.ternarize_pack(wt))               # same bytes as the single call
+    assert torch.all(arena[off:] == 0xEE)
+    fresh = ops.ternarize_pack_batch(ws[:3], 0.25, "binary")                     # allocating form, another quantizer
+    for f, wt in zip(fresh, ws[:3]):
+        assert np.array_equal(f.cpu().numpy(), O.pack_format_c(O.binarize_sign(wt.float().cpu().numpy())))
+    assert ops.ternarize_pack_batch([]) == []
+    with pytest.raises(ValueError):
+        ops.ternarize_pack_batch([ws[0], ws[1].to(torch.float64 if dtype != torch.float32 else torch.float16)])
+    with pytest.raises(ValueError):
+        ops.ternarize_pack_batch(ws[:2], outs=views[:1])
+
+
 def test_ternarize_pack_full_size(ops, dev):
     """4096 x 4096 (the benchmark's weight matrix): every byte against the oracle."""
     g = torch.Generator(device="cpu").manual_seed(1234)
