@@ -390,12 +390,21 @@ def main():
             shapes = [(6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192)] * 22
             lat = [torch.rand(n_, k_, device=dev) * 2 - 1 for (n_, k_) in shapes]
             dst = [torch.empty((n_, k_ // 4), dtype=torch.uint8, device=dev) for (n_, k_) in shapes]
-            a_avg, _ = time_launches(lambda i: ops.ternarize_pack_batch(lat, 0.5, "ternary", outs=dst), 3, 1, rounds=3)
+            a_avg, _, a_how = time_graph(lambda i: ops.ternarize_pack_batch(lat, 0.5, "ternary", outs=dst), 3, 1, rounds=3)
             a_bytes = sum(n_ * k_ * 4 + n_ * k_ // 4 for (n_, k_) in shapes)
-            hbm["pack_arena"] = {"kernel": "tvl::quantize_pack_batch_kernel<float, ternary> (32 matrices per launch)", "layers": len(shapes),
+            hbm["pack_arena"] = {"kernel": "tvl::quantize_pack_batch_kernel<float, ternary> (up to 64 matrices per launch)", "layers": len(shapes), "timing": a_how,
                                  "algorithmic_bytes": a_bytes, "avg_call_ms": round(a_avg, 4), "GBps": round(a_bytes / (a_avg * 1e-3) / 1e9, 1),
                                  "frac_of_hbm_peak": round(a_bytes / (a_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del lat, dst
+            # one large matrix (1 GiB of latent weights): the kernel's rate without launch ramps and tails
+            big_w = torch.rand(16384, 16384, device=dev) * 2 - 1
+            big_o = torch.empty((16384, 4096), dtype=torch.uint8, device=dev)
+            b_avg, _, b_how = time_graph(lambda i: ops.ternarize_pack(big_w, 0.5, out=big_o), 3, 1, rounds=3)
+            b_bytes = 16384 * 16384 * 4 + 16384 * 4096
+            hbm["pack_16384"] = {"kernel": "tvl::quantize_pack_fast_kernel<float, ternary>", "shape": [16384, 16384], "timing": b_how,
+                                 "algorithmic_bytes": b_bytes, "avg_launch_ms": round(b_avg, 4), "GBps": round(b_bytes / (b_avg * 1e-3) / 1e9, 1),
+                                 "frac_of_hbm_peak": round(b_bytes / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del big_w, big_o
             # ---- HBM-bound form of the matmul: few activation rows (decode / small batches), weights streamed once from HBM.
             # 16384 x 16384 (64 MiB packed, 10 rotating copies) is large enough to leave the launch-latency regime.
             for (dm, dn, dk, tag) in ((1, 16384, 16384, "decode_m1_16384"), (1, N, K, "decode_m1"), (16, N, K, "rows16"), (64, N, K, "rows64"),

@@ -121,7 +121,7 @@ class PackedArena:
         packed = torch.full((off,), 0x55, dtype=torch.uint8, device=device)  # pad bytes = four zeros
         scales = torch.empty((voff,), dtype=torch.float32, device=device)
         biases = torch.zeros((voff,), dtype=torch.float32, device=device)
-        pending = {}   # quantization -> (latent weights, arena views): packed together, one launch per 32 layers
+        pending = {}   # quantization -> (latent weights, arena views): packed together, one launch per 64 layers
         for e in entries:
             w, scale, bias = fetch(e.name)
             if tuple(w.shape) != (e.n, e.k) or scale.numel() != e.n or (bias is not None and bias.numel() != e.n):

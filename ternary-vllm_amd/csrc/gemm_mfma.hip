@@ -172,7 +172,7 @@ struct TileCost { int kind, bm, bn, occupancy; double fixed_us, step_light_us, s
 static const TileCost TILE_COSTS[] = {
     {KIND_BIG, 256, 256, 1, 14.0, 1.20, 1.57, 1.57},    // 8 waves, 96 / 128 KiB LDS
     {KIND_MID, 128, 256, 1, 7.0, 0.62, 0.84, 0.84},     // 8 waves, 64 KiB LDS
-    {KIND_MID, 128, 128, 2, 6.0, 0.42, 0.47, 0.44},     // 4 waves, 64 KiB LDS
+    {KIND_MID, 128, 128, 2, 6.0, 0.42, 0.47, 0.49},     // 4 waves, 64 KiB LDS
     {KIND_SMALL, 64, 128, 2, 4.5, 0.45, 0.45, 0.39},
     {KIND_SMALL, 32, 128, 3, 4.0, 0.21, 0.21, 0.21},
 };
@@ -215,6 +215,8 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_byte
                        (double)per * (q == 1 ? (load <= 0.6 ? tc.step_light_us : tc.step_full_us) : (double)q * tc.step_shared_us);
             // the 256 x 256 tile walks its q tiles per CU as one stream of k steps: the fixed cost once, ~4 us of epilogue per tile
             if (tc.kind == KIND_BIG && q > 1) t = tc.fixed_us + (double)q * ((double)per * tc.step_full_us + 4.0);
+            // so does the 128 x 256 tile (gemm_mid.hip), at ~6 us per tile for its epilogue under the next tile's first steps
+            if (tc.kind == KIND_MID && tc.bn == 256 && s == 1 && tiles > cus) t = tc.fixed_us + load * ((double)per * 0.9 + 6.0);
             if (s > 1) t += 3.0 + 3.0 * (double)s * (double)m * (double)n * 4.0 / 8.0e6;
             if (t < best_t) { best_t = t; best = GemmPlan{tc.kind, tc.bm, tc.bn, (int)s}; }
         }

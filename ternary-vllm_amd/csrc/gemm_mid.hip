@@ -9,6 +9,8 @@
 
 #include <stdlib.h>
 
+#include <stdlib.h>
+
 namespace tvl {
 
 constexpr int MID_NB = 4;   // activation tiles in LDS: a tile is requested two steps before its use
@@ -35,9 +37,23 @@ static int launch_mid_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const
         return launch_splitk_reduce(slab, splits, m, n, scale, bias, clip, act, act_begin, y,
                                     std::is_same<TY, float>::value ? TVL_F32 : (std::is_same<TY, f16>::value ? TVL_F16 : TVL_BF16), ld_y, st);
     }
+    // Many more tiles than compute units (tall activations, short k: the ViT shapes): one workgroup per CU walks its tiles as one
+    // stream of k steps, the next tile's loads running under the current tile's epilogue (TVL_MID_PERSIST=0/1 pins it: tuning).
+    static const int force_persist = [] { const char* e = getenv("TVL_MID_PERSIST"); return e ? atoi(e) : -1; }();
+    const int cus = device_cu_count();
+    const bool persist = WAVES == 8 && nblk > cus && force_persist != 0;
 #define TVL_MID(HB, ACT)                                                                                                    \
     do {                                                                                                                    \
-        auto kern = gemm_mfma16_kernel<TX, TY, HB, ACT, 1, false, MID_NB, BM, WAVES, false, (WAVES == 4 ? 3 : 2)>;                              \
+        if constexpr (WAVES == 8) {                                                                                         \
+            if (persist) {                                                                                                  \
+                auto kp = gemm_mfma16_kernel<TX, TY, HB, ACT, 1, true, MID_NB, BM, WAVES, false, 2>;                        \
+                if ((rc = set_dynamic_lds_limit((const void*)kp, lds_bytes)) != TVL_OK) return rc;                          \
+                hipLaunchKernelGGL(kp, dim3(cus), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, \
+                                   act_begin, y, ld_y, tiles_n, nblk, w_steps, 0);                                          \
+                break;                                                                                                      \
+            }                                                                                                               \
+        }                                                                                                                   \
+        auto kern = gemm_mfma16_kernel<TX, TY, HB, ACT, 1, false, MID_NB, BM, WAVES, false, (WAVES == 4 ? 3 : 2)>;          \
         if ((rc = set_dynamic_lds_limit((const void*)kern, lds_bytes)) != TVL_OK) return rc;                                \
         hipLaunchKernelGGL(kern, dim3(nblk), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, \
                            act_begin, y, ld_y, tiles_n, nblk, w_steps, 0);                                                  \

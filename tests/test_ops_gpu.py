@@ -171,10 +171,10 @@ def test_ternarize_pack_threshold_and_strides(ops, dev):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 def test_ternarize_pack_batch_matches_single_calls_and_oracle(ops, dev, dtype):
     """Many matrices in one launch (a checkpoint's layers into an arena): the bytes of the single-matrix calls and of the oracle.
-    40 matrices cross the 32-per-launch limit; odd k, a misaligned view and an empty matrix take the per-matrix path; the
+    70 matrices cross the 64-per-launch limit; odd k, a misaligned view and an empty matrix take the per-matrix path; the
     destinations are row-padded views into one buffer whose pad bytes must stay untouched."""
     rng = np.random.default_rng(17)
-    shapes = [(int(rng.integers(1, 70)), 16 * int(rng.integers(1, 200))) for _ in range(36)] + [(5, 1030), (3, 7), (0, 64), (4, 2048)]
+    shapes = [(int(rng.integers(1, 70)), 16 * int(rng.integers(1, 200))) for _ in range(66)] + [(5, 1030), (3, 7), (0, 64), (4, 2048)]
     ws, outs, views, want = [], [], [], []
     arena = torch.full((sum(n * (-(-((k + 3) // 4) // 16) * 16) for n, k in shapes) + 64,), 0xEE, dtype=torch.uint8, device=dev)
     off = 0

@@ -3,7 +3,7 @@
 import csv
 import sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(t in r["Kernel_Name"] for t in ("gemm_skinny", "gemm_stream", "gemv_kernel", "gemm_mfma", "gemm_generic", "splitk_reduce"))]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(t in r["Kernel_Name"] for t in ("gemm_skinny", "gemm_stream", "gemv_kernel", "gemm_mfma", "gemm_generic", "gemm_rows", "splitk_reduce"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 reps = int(sys.argv[2])
 calls = []  # each call: list of (name, dur)
@@ -22,6 +22,6 @@ for spec in sys.argv[3:]:
     med = tot[len(tot) // 2] / 1e3
     main = sorted(c[0][1] for c in mine)[len(mine) // 2] / 1e3
     byts = m * k * 2 + n * k // 4 + 8 * n + m * n * 2
-    kern = "gemv" if "gemv" in mine[0][0][0] else "stream" if "stream" in mine[0][0][0] else "skinny" if "skinny" in mine[0][0][0] else ("mfma" if "mfma" in mine[0][0][0] else "generic")
+    kern = "rows" if "gemm_rows" in mine[0][0][0] else "gemv" if "gemv" in mine[0][0][0] else "stream" if "stream" in mine[0][0][0] else "skinny" if "skinny" in mine[0][0][0] else ("mfma" if "mfma" in mine[0][0][0] else "generic")
     print(f"{spec:>18s}  {kern:7s} kernels/call {len(mine[0])}  median total {med:8.2f} us (main {main:8.2f})  "
           f"{2.0 * m * n * k / med / 1e6:9.1f} TFLOP/s  {byts / med / 1e3:8.1f} GB/s ({byts / med / 1e3 / 80:5.1f} % of 8 TB/s)")
