@@ -357,15 +357,21 @@ def main():
         achieved_tf = flops / (avg_ms * 1e-3) / 1e12
         by = gemm_bytes(M, N, K, 2)
         big = (M + 255) // 256 * ((N + 255) // 256) >= 192
-        traffic = None
-        try:   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (only valid for the profiled shape)
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                if (M, N, K) == (4096, 4096, 4096):
-                    traffic = json.load(f)["gemm_4096x4096x4096_f16"]["traffic_bytes"]
+        traffic, traffic_note = None, None
+        try:   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes: valid for the profiled binary and shape only
+            import hashlib
+            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+                tj = json.load(f)
+            with open(ops.LIBRARY_PATH, "rb") as f:
+                same_binary = hashlib.sha256(f.read()).hexdigest() == tj.get("library_sha256")
+            if (M, N, K) == (4096, 4096, 4096) and same_binary:
+                traffic = tj["gemm_4096x4096x4096_f16"]["traffic_bytes"]
+            elif (M, N, K) == (4096, 4096, 4096):
+                traffic_note = "profiles/r02_traffic.json was collected with another build of the library: not reported"
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved_tf / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(achieved_tf / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": "tvl::gemm_mfma16_kernel<f16, f16, bias, none> (256x256 tile, v_mfma_f32_16x16x32_f16)" if big else "tvl::gemm_mfma_kernel (small tiles / split-K)",
                     "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops,
                     "timing": f"one HIP event pair around the {args.steps} timed launches on the launch stream"}

@@ -155,7 +155,10 @@ gemm_rows_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
 // Every workgroup reads all of x through L2 (16 or 32 channels per workgroup), so the kernel's time grows with m * n * k:
 // measured (us, n = k = 4096) 5.1 / 5.7 / 6.5 / 8.5 at m = 2 / 4 / 8 / 16 against 5.4 / 8.2 / 10.2 / 11.4 for the kernels
 // that split k over workgroups and reduce in a second launch, but 25 against 19 at 16 x 8192 x 8192, where the
-// activation traffic (m k n / 8 bytes) outgrows the weight stream.  It is used where it wins: 3 .. 16 rows (one or two rows
+// activation traffic (m k n / 8 bytes) outgrows the weight stream.  (Built and dropped for those layers: the four waves on
+// different channels of one k range with its activations staged once in LDS, k split over workgroups, slabs + reduce launch -
+// 48 us at 16 x 16384 x 16384 against 39 us for the older streaming kernel: the 16-channel x 64-byte weight pieces, half a
+// cache line per channel, stream at ~2 TB/s whatever feeds the other operand.)  It is used where it wins: 3 .. 16 rows (one or two rows
 // go to the table-lookup kernel) up to m n k = 3e8, and 17 .. 32 rows on small layers.
 bool gemm_rows_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw) {
     if (x_dtype != TVL_F16 && x_dtype != TVL_BF16) return false;

@@ -1,8 +1,7 @@
-# usage: bash tools/rows_sweep.sh <out.jsonl> "<shapes>" "<waves list, 0 = library choice>"
+# usage: bash tools/rows_sweep.sh <out.jsonl> "<shapes>"   (each shape with TVL_ROWS_LDS = 0 and 1)
 set -e
-OUT=$1; S=$2; WV=${3:-0}
+OUT=$1; S=$2
 mkdir -p $(dirname $OUT)
-TVL_ROWS_KERNEL=0 timeout -k 10 200 python tools/time_plans.py $S | sed "s/^{/{\"rows\": 0, \"waves\": 0, /" >> $OUT
-for W in $WV; do
-  TVL_ROWS_WAVES=$W TVL_ROWS_KERNEL=1 timeout -k 10 200 python tools/time_plans.py $S | sed "s/^{/{\"rows\": 1, \"waves\": $W, /" >> $OUT
+for L in 0 1; do
+  TVL_ROWS_LDS=$L timeout -k 10 300 python tools/time_plans.py $S | sed "s/^{/{\"lds\": $L, /" >> $OUT
 done
