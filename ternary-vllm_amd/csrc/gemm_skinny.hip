@@ -255,8 +255,7 @@ static int launch_skinny_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, co
         const int per = (int)ceil_div(total_ss, splits);
         splits = (int)ceil_div(total_ss, per);
         auto kern = gemm_skinny_kernel<TX, float, BKS, ROWS, false, TVL_ACT_NONE, true>;
-        if (lds_bytes > 48 * 1024)
-            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (int rc_ = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc_ != TVL_OK) return rc_;
         hipLaunchKernelGGL(kern, dim3(nblk, splits), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip,
                            0, slab, n, per);
         TVL_LAUNCH_CHECK();
@@ -265,8 +264,7 @@ static int launch_skinny_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, co
 #define TVL_SK(HB, ACT)                                                                                            \
     do {                                                                                                           \
         auto kern = gemm_skinny_kernel<TX, TY, BKS, ROWS, HB, ACT, false>;                                                \
-        if (lds_bytes > 48 * 1024)                                                                                 \
-            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        if (int rc_ = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc_ != TVL_OK) return rc_; \
         hipLaunchKernelGGL(kern, dim3(nblk, 1), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act_begin, y, ld_y, 0); \
     } while (0)
     if (bias) {

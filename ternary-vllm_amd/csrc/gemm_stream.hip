@@ -329,8 +329,7 @@ static int launch_stream_cfg(const f16* x, int64_t m, int64_t k, int64_t ld_x, c
     const dim3 block(256);
     if (p.splits > 1) {
         auto kern = gemm_stream_kernel<TY, TILES, RA, D, true>;
-        if (lds_bytes > 48 * 1024)
-            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (int rc_ = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc_ != TVL_OK) return rc_;
         hipLaunchKernelGGL(kern, dim3(nblk, p.splits), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, act_begin,
                            y, ld_y, p.per, reinterpret_cast<float*>(ws));
         TVL_LAUNCH_CHECK();
@@ -338,8 +337,7 @@ static int launch_stream_cfg(const f16* x, int64_t m, int64_t k, int64_t ld_x, c
                                     std::is_same<TY, float>::value ? TVL_F32 : (std::is_same<TY, f16>::value ? TVL_F16 : TVL_BF16), ld_y, st);
     } else {
         auto kern = gemm_stream_kernel<TY, TILES, RA, D, false>;
-        if (lds_bytes > 48 * 1024)
-            TVL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (int rc_ = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc_ != TVL_OK) return rc_;
         hipLaunchKernelGGL(kern, dim3(nblk, 1), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, act_begin,
                            y, ld_y, 0, (float*)nullptr);
     }

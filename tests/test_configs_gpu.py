@@ -98,3 +98,17 @@ def test_headline_4096_full_output_and_randn_rows(ops, dev, c_oracle):
     rel_gpu, rel_cpu = float(np.max(np.abs(got[rows] - want64) / mag)), float(np.max(np.abs(cpu32 - want64) / mag))
     print(f"4096^3 N(0,1) f16: max|gpu - f64| = {err_gpu:.3e} ({rel_gpu:.2e} of sum|terms|), max|cpu f32 - f64| = {err_cpu:.3e} ({rel_cpu:.2e})")
     assert rel_gpu <= max(2.0 * rel_cpu, 2.0 ** -22)
+
+
+@pytest.mark.parametrize("method", ["select", "matmul"])
+def test_config1_ternary_mm_at_the_files_own_size(ops, dev, method):
+    """matrix_mul_tests.py:8-9,16-18: 1024 x 1024 operands, half of the weights zeroed.  Grid activations, so the select-and-sum
+    loop's float32 sums are exact and the result must equal the numpy restatement of the reference loop bit for bit."""
+    rng = np.random.default_rng(1024)
+    m_ = rng.integers(-64, 65, size=(1024, 1024)).astype(np.float32) / 64.0
+    tm = rng.normal(size=(1024, 1024)).astype(np.float32)
+    tm[rng.random(size=tm.shape) < 0.5] = 0.0
+    want = O.ternary_mm(m_, tm)
+    got = ops.ternary_mm(torch.from_numpy(m_).to(dev), torch.from_numpy(tm).to(dev), method)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(want, m_ @ np.sign(tm).T)
