@@ -112,3 +112,25 @@ def test_config1_ternary_mm_at_the_files_own_size(ops, dev, method):
     got = ops.ternary_mm(torch.from_numpy(m_).to(dev), torch.from_numpy(tm).to(dev), method)
     assert np.array_equal(got.cpu().numpy(), want)
     assert np.array_equal(want, m_ @ np.sign(tm).T)
+
+
+PLANS = ["2:256:256:1", "1:128:256:1", "1:128:256:3", "1:128:128:1", "1:128:128:4", "0:64:128:1", "0:64:128:3", "0:32:128:2", "0:128:128:2"]
+
+
+@pytest.mark.parametrize("plan", PLANS)
+def test_every_tile_plan_is_exact_when_pinned(plan):
+    """The planner picks a tile and a split-K factor per shape, so a test shape exercises one of them.  Here every tile of the
+    matrix-core kernels (256 x 256, 128 x 256, 128 x 128, the 64- and 32-row tiles) is pinned in turn, with and without split-K,
+    on ragged shapes (edge tiles, odd step counts, float32 activations as three wrapped bf16 planes, the activation from a
+    channel on, code 3) in a child process - the library reads TVL_FORCE_PLAN once - and compared with the CPU oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = ["300,500,512", "129,257,64", "1000,130,1280", "520,2304,192"]
+    if plan.startswith("1:128:256:1"):
+        shapes.append("9000,1100,128")            # more tiles than compute units: the persistent form of the 128 x 256 tile
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_plan.py"), *shapes], env=dict(os.environ, TVL_FORCE_PLAN=plan),
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert out.stdout.count(": ok") == 6 * len(shapes)
