@@ -173,7 +173,7 @@ static const TileCost TILE_COSTS[] = {
     {KIND_BIG, 256, 256, 1, 14.0, 1.20, 1.57, 1.57},    // 8 waves, 96 / 128 KiB LDS
     {KIND_MID, 128, 256, 1, 7.0, 0.62, 0.84, 0.84},     // 8 waves, 64 KiB LDS
     {KIND_MID, 128, 128, 2, 6.0, 0.42, 0.47, 0.49},     // 4 waves, 64 KiB LDS
-    {KIND_SMALL, 64, 128, 2, 4.5, 0.45, 0.45, 0.39},
+    {KIND_MID, 64, 128, 4, 5.0, 0.28, 0.36, 0.30},      // 4 waves, 32 KiB LDS
     {KIND_SMALL, 32, 128, 3, 4.0, 0.21, 0.21, 0.21},
 };
 
@@ -204,7 +204,7 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_byte
     double best_t = 1e30;
     for (const TileCost& tc : TILE_COSTS) {
         if (tc.bm > 32 && m <= tc.bm / 2) continue;   // more than half of the tile's rows would be padding
-        if (tc.kind == KIND_SMALL && m > 3 * tc.bm / 2) continue;   // few rows per decoded weight: only where the 128-row tiles would be mostly padding
+        if ((tc.bm == 64 && m > 192) || (tc.bm == 32 && m > 48)) continue;   // few rows per decoded weight: only where taller tiles would be mostly padding
         const int64_t tiles = ceil_div(m, tc.bm) * ceil_div(n, tc.bn);
         for (int64_t s = 1; s <= 64; ++s) {
             if (s > 1 && (s > max_by_ws || steps / s < 2 || tc.kind == KIND_BIG)) break;
@@ -240,7 +240,7 @@ static int launch_mfma_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const
                                p.splits, slab, w_steps, st);
     if (p.bm == 128)   // (only by TVL_FORCE_PLAN: the 32x32x16 kernel's 128 x 128 tile, superseded by the mid-size kernel)
         return launch_cfg<TX, TY, 128, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, slab, w_steps, st);
-    if (p.bm == 64)
+    if (p.bm == 64)   // (only by TVL_FORCE_PLAN, like the 128 x 128 tile above)
         return launch_cfg<TX, TY, 64, 128, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, slab, w_steps, st);
     return launch_cfg<TX, TY, 32, 128, 1, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, p.splits, slab, w_steps, st);
 }

@@ -76,6 +76,8 @@ static int launch_mid_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const 
         return launch_mid_cfg<TX, TY, 128, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, splits, slab, w_steps, st);
     if (bm == 128 && bn == 128)
         return launch_mid_cfg<TX, TY, 128, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, splits, slab, w_steps, st);
+    if (bm == 64 && bn == 128)
+        return launch_mid_cfg<TX, TY, 64, 4>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, splits, slab, w_steps, st);
     set_error("ternary_matmul: no %d x %d tile in the mid-size kernel", bm, bn);
     return TVL_ERR_INVALID;
 }

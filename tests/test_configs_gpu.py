@@ -114,7 +114,7 @@ def test_config1_ternary_mm_at_the_files_own_size(ops, dev, method):
     assert np.array_equal(want, m_ @ np.sign(tm).T)
 
 
-PLANS = ["2:256:256:1", "1:128:256:1", "1:128:256:3", "1:128:128:1", "1:128:128:4", "0:64:128:1", "0:64:128:3", "0:32:128:2", "0:128:128:2"]
+PLANS = ["2:256:256:1", "1:128:256:1", "1:128:256:3", "1:128:128:1", "1:128:128:4", "1:64:128:1", "1:64:128:5", "0:64:128:3", "0:32:128:2", "0:128:128:2"]
 
 
 @pytest.mark.parametrize("plan", PLANS)
