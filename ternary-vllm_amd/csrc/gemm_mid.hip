@@ -9,8 +9,6 @@
 
 #include <stdlib.h>
 
-#include <stdlib.h>
-
 namespace tvl {
 
 constexpr int MID_NB = 4;   // activation tiles in LDS: a tile is requested two steps before its use

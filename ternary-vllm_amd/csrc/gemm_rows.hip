@@ -1,4 +1,5 @@
-// Packed-ternary x f16 / bf16 product for few activation rows (decode batches of 3 .. 32 rows), ONE launch.
+// Packed-ternary x f16 / bf16 product for few activation rows (decode batches of 3 .. 64 rows): a one-launch kernel for small
+// layers (first half of this file) and a kernel that shares the activations through LDS for larger ones (second half).
 //
 // The work is a weight stream: at m = 16, n = k = 4096 the packed weights are 4 MiB against 128 KiB of activations.
 // A workgroup owns 16 * CT output channels and ALL rows; its waves split the k range (each wave a contiguous
@@ -17,7 +18,39 @@
 // Requires k % 256 == 0, 16-byte aligned activation rows and packed rows.
 #include "gemm_mfma_kernels.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 namespace tvl {
+
+
+// One lane's share of a 16 x 16 result fragment: row gm, channels cn .. cn + 3 (epilogue, conversion, 8- or 16-byte store).
+__device__ __forceinline__ void rows_store_fragment(floatx4 s, int gm, int cn, int m, int n, const float* __restrict__ scale,
+                                                    const float* __restrict__ bias, bool has_bias, int act, float cl, int act_begin,
+                                                    void* __restrict__ y, int y_dtype, int64_t ld_y) {
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        o[e] = epilogue_rt(s[e], cn + e < n ? scale[cn + e] : 0.0f, (has_bias && cn + e < n) ? bias[cn + e] : 0.0f, has_bias, act, cl, cn + e, act_begin);
+    if (gm >= m) return;
+    if (y_dtype == TVL_F32) {
+        float* yrow = reinterpret_cast<float*>(y) + (int64_t)gm * ld_y;
+        if (cn + 4 <= n && ((reinterpret_cast<uintptr_t>(yrow + cn)) & 15) == 0) *reinterpret_cast<float4*>(yrow + cn) = make_float4(o[0], o[1], o[2], o[3]);
+        else
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (cn + e < n) yrow[cn + e] = o[e];
+    } else {
+        uint16_t h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            h[e] = y_dtype == TVL_F16 ? __builtin_bit_cast(uint16_t, from_float<f16>(o[e])) : from_float<bf16_t>(o[e]).v;
+        uint16_t* yrow = reinterpret_cast<uint16_t*>(y) + (int64_t)gm * ld_y;
+        if (cn + 4 <= n && ((reinterpret_cast<uintptr_t>(yrow + cn)) & 7) == 0) *reinterpret_cast<uint2*>(yrow + cn) = *reinterpret_cast<const uint2*>(h);
+        else
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (cn + e < n) yrow[cn + e] = h[e];
+    }
+}
 
 template <typename TX, int MR, int CT, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
@@ -126,40 +159,15 @@ gemm_rows_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
         floatx4 s = red[0][f][lane];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) s += red[w][f][lane];
-        const int gm = 16 * i + c, cn = n0 + 16 * t + 4 * g;
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            o[e] = epilogue_rt(s[e], cn + e < n ? scale[cn + e] : 0.0f, (has_bias && cn + e < n) ? bias[cn + e] : 0.0f, has_bias, act, cl, cn + e, act_begin);
-        if (gm >= m) continue;
-        if (y_dtype == TVL_F32) {
-            float* yrow = reinterpret_cast<float*>(y) + (int64_t)gm * ld_y;
-            if (cn + 4 <= n && ((reinterpret_cast<uintptr_t>(yrow + cn)) & 15) == 0) *reinterpret_cast<float4*>(yrow + cn) = make_float4(o[0], o[1], o[2], o[3]);
-            else
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (cn + e < n) yrow[cn + e] = o[e];
-        } else {
-            uint16_t h[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                h[e] = y_dtype == TVL_F16 ? __builtin_bit_cast(uint16_t, from_float<f16>(o[e])) : from_float<bf16_t>(o[e]).v;
-            uint16_t* yrow = reinterpret_cast<uint16_t*>(y) + (int64_t)gm * ld_y;
-            if (cn + 4 <= n && ((reinterpret_cast<uintptr_t>(yrow + cn)) & 7) == 0) *reinterpret_cast<uint2*>(yrow + cn) = *reinterpret_cast<const uint2*>(h);
-            else
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (cn + e < n) yrow[cn + e] = h[e];
-        }
+        rows_store_fragment(s, 16 * i + c, n0 + 16 * t + 4 * g, m, n, scale, bias, has_bias, act, cl, act_begin, y, y_dtype, ld_y);
     }
 }
 
 // Every workgroup reads all of x through L2 (16 or 32 channels per workgroup), so the kernel's time grows with m * n * k:
 // measured (us, n = k = 4096) 5.1 / 5.7 / 6.5 / 8.5 at m = 2 / 4 / 8 / 16 against 5.4 / 8.2 / 10.2 / 11.4 for the kernels
 // that split k over workgroups and reduce in a second launch, but 25 against 19 at 16 x 8192 x 8192, where the
-// activation traffic (m k n / 8 bytes) outgrows the weight stream.  (Built and dropped for those layers: the four waves on
-// different channels of one k range with its activations staged once in LDS, k split over workgroups, slabs + reduce launch -
-// 48 us at 16 x 16384 x 16384 against 39 us for the older streaming kernel: the 16-channel x 64-byte weight pieces, half a
-// cache line per channel, stream at ~2 TB/s whatever feeds the other operand.)  It is used where it wins: 3 .. 16 rows (one or two rows
-// go to the table-lookup kernel) up to m n k = 3e8, and 17 .. 32 rows on small layers.
+// activation traffic (m k n / 8 bytes) outgrows the weight stream: larger layers go to gemm_rows_shared_kernel below.  It is used
+// where it wins: 3 .. 16 rows (one or two rows go to the table-lookup kernel) up to m n k = 3e8, and 17 .. 32 rows on small layers.
 bool gemm_rows_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw) {
     if (x_dtype != TVL_F16 && x_dtype != TVL_BF16) return false;
     if (m < 3 || m > 32 || k <= 0 || k % 256 != 0) return false;
@@ -206,6 +214,299 @@ int launch_gemm_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t l
     }
     if (x_dtype == TVL_F16) return launch_rows_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
     return launch_rows_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+}
+
+// ---- larger layers, up to 64 rows: the weight stream of 8 waves shares one copy of the activations in LDS --------------------
+//
+// Above, every wave fetches its own activation fragments from L2: 8 KiB per KiB of weights at 16 rows, in 16-byte pieces 128
+// bytes apart (64 cache lines per load instruction), which bounds that kernel once the layer is large (16 x 16384 x 16384:
+// 38 us, 1.7 TB/s of weights; a read-only probe with the same 16-channel x 64-byte weight pieces streams 5.5 TB/s from cold HBM -
+// tools/hwtests/bw_probe.hip - so the weight pieces are not the limit).  Here a workgroup is 8 waves on 8 x 16 CT consecutive
+// channels and ONE k range.  The activations of the range pass through LDS in chunks of CS steps, double-buffered:
+//   * staging: wave w brings rows 2 w, 2 w + 1 of every 16-row block, half a wave per row - 32 lanes x 16 bytes, whole cache
+//     lines - and writes each piece where the fragment layout wants it (fragment j = piece & 7, lane group piece >> 3; fragments
+//     are padded to 65 x 16 bytes so the writes spread over the banks); a fragment is read back with one conflict-free
+//     ds_read_b128 per lane, in blocks requested before the previous block is multiplied;
+//   * memory returns loads in issue order, so waiting for a chunk of activations also waits for every weight load issued before
+//     it: a chunk is requested two chunks (DEPTH steps) before its use and written to LDS one chunk before - the weight loads older
+//     than it are then the ones the next step needs anyway, and the weight stream (DEPTH steps in flight per wave, registers) never
+//     drains early;
+//   * one barrier per chunk.
+// k is split over blockIdx.y where the channel blocks alone do not fill the chip (float32 slabs + the deterministic reduce of
+// gemm_mfma.hip).  What bounds it now is instruction issue: per 256-deep step a wave decodes 64 weights per lane (about 90
+// vector-ALU instructions) for 8 matrix instructions, and the two waves of a SIMD do not overlap that work fully (per-step
+// timestamps: a step takes ~800 cycles for the first wave of a SIMD and ~1600 for the second while both are in the same step);
+// two workgroups per compute unit, 8 steps in flight and 32 channels per wave all measured no faster.
+template <typename TX, int MR, int CT, int CS, bool SPLIT>
+__global__ void __launch_bounds__(512)
+gemm_rows_shared_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
+                        const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act, int act_begin, void* __restrict__ y,
+                        int y_dtype, int64_t ld_y, int steps_per_split, float* __restrict__ slab) {
+    constexpr int DEPTH = 4;          // steps of weights in flight per wave (8 measured no faster)
+    constexpr int FS = 65;            // uint4 per fragment in LDS: 64 lanes + 1 of padding (spreads the staging writes over the banks)
+    constexpr int IMG = 8 * FS;       // uint4 per 16-row step image
+    static_assert(DEPTH % (2 * CS) == 0, "a group of DEPTH steps is an even number of chunks");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint4* xbuf = reinterpret_cast<uint4*>(lds_raw);   // [2 buffers][CS steps][MR row blocks][8 fragments][FS]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * (128 * CT) + wave * (16 * CT);
+    const int total = k / 256;
+    const int s_begin = SPLIT ? (int)blockIdx.y * steps_per_split : 0;
+    const int ns = SPLIT ? (total - s_begin < steps_per_split ? total - s_begin : steps_per_split) : total;
+    const int last = ns - 1;
+
+    const uint4* wp[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        int gn = n0 + 16 * t + c;
+        gn = gn < n ? gn : n - 1;
+        wp[t] = reinterpret_cast<const uint4*>(pw + (int64_t)gn * ld_pw + (int64_t)s_begin * 64 + 16 * g);
+    }
+    // staging: wave w brings rows 2 w, 2 w + 1 of every 16-row block, half a wave per row: 32 lanes x 16 bytes = the 512 contiguous
+    // bytes of one step (whole cache lines).  Piece p (k = 8 p .. 8 p + 7) belongs to fragment j = p & 7, lane group p >> 3.
+    const int st_row = 2 * wave + (lane >> 5), st_p = lane & 31;
+    const uint4* xs[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        int gm = 16 * i + st_row;
+        gm = gm < m ? gm : m - 1;
+        xs[i] = reinterpret_cast<const uint4*>(x + (int64_t)gm * ld_x + (int64_t)s_begin * 256 + 8 * st_p);
+    }
+    const int st_dst = (st_p & 7) * FS + (st_p >> 3) * 16 + st_row;   // uint4 index inside one 16-row step image
+    floatx4 acc[MR][CT];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[i][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    const DecodeConsts dc = make_decode_consts();
+
+    auto load_w = [&](int s, uint4 (&w)[CT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const nts_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nts_u32x4*>(wp[t] + (int64_t)s * 4));
+            w[t] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto stage_load = [&](int chunk, nts_u32x4 (&st)[CS][MR]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int sl = 0; sl < CS; ++sl) {
+            int s = chunk * CS + sl;
+            s = s < last ? s : last;             // past the range: the last step again (never multiplied)
+#pragma unroll
+            for (int i = 0; i < MR; ++i) st[sl][i] = *reinterpret_cast<const nts_u32x4*>(xs[i] + (int64_t)s * 32);
+        }
+    };
+    auto stage_store = [&](int buf, const nts_u32x4 (&st)[CS][MR]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int sl = 0; sl < CS; ++sl)
+#pragma unroll
+            for (int i = 0; i < MR; ++i) *reinterpret_cast<nts_u32x4*>(xbuf + ((buf * CS + sl) * MR + i) * IMG + st_dst) = st[sl][i];
+    };
+    // One step: the 8 fragments are read from LDS in blocks of JB, each block requested before the previous one is multiplied (a read
+    // issued right before its use costs the full LDS latency, and two waves per SIMD do not hide it).
+    constexpr int JB = MR == 1 ? 4 : (MR == 2 ? 2 : 1), NBLK = 8 / JB;
+    auto read_block = [&](int buf, int sl, int blk, uint4 (&xf)[JB][MR]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                xf[jj][i] = xbuf[((buf * CS + sl) * MR + i) * IMG + (blk * JB + jj) * FS + lane];
+    };
+    auto compute_block = [&](int blk, const uint4 (&w)[CT], const uint4 (&xf)[JB][MR]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+            const int j = blk * JB + jj;   // dword j >> 1 of the lane's 16 bytes, halfword j & 1
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const uint32_t d = (j >> 1) == 0 ? w[t].x : (j >> 1) == 1 ? w[t].y : (j >> 1) == 2 ? w[t].z : w[t].w;
+                const uint4 a = (j & 1) ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc);
+#pragma unroll
+                for (int i = 0; i < MR; ++i) acc[i][t] = mfma16<TX>(a, xf[jj][i], acc[i][t]);
+            }
+        }
+    };
+    auto compute_step = [&](int buf, int sl, const uint4 (&w)[CT]) __attribute__((always_inline)) {
+        uint4 xa[JB][MR], xb[JB][MR];
+        read_block(buf, sl, 0, xa);
+#pragma unroll
+        for (int blk = 0; blk < NBLK; blk += 2) {
+            read_block(buf, sl, blk + 1, xb);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_block(blk, w, xa);
+            if (blk + 2 < NBLK) read_block(buf, sl, blk + 2, xa);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_block(blk + 1, w, xb);
+        }
+    };
+
+    {
+        uint4 w0[CT], w1[CT], w2[CT], w3[CT];
+        // Memory returns loads in issue order, so waiting for a chunk of activations also waits for every weight load issued
+        // before it.  A chunk is therefore requested TWO chunks (DEPTH steps) before its use and written to LDS one chunk before:
+        // the weight loads older than it are then the ones the next step needs anyway, and the stream never drains early.
+        nts_u32x4 sta[CS][MR], stb[CS][MR];   // even / odd chunks (separate arrays: one indexed array ends up in scratch memory)
+        stage_load(0, sta);
+        stage_load(1, stb);
+        load_w(0, w0);
+        load_w(1 < last ? 1 : last, w1);
+        load_w(2 < last ? 2 : last, w2);
+        load_w(3 < last ? 3 : last, w3);
+        stage_store(0, sta);
+        __syncthreads();
+        // step s + Q of a group of DEPTH steps; Q is a literal, so chunk boundaries, LDS buffer and staging registers are known at
+        // compile time (s is a multiple of DEPTH, DEPTH / CS is even: chunk (s + Q) / CS has the parity of Q / CS).  Past the end of
+        // the range only the multiplication is skipped: loads (clamped to the last step), LDS writes and barriers run
+        // unconditionally, so no register is live across a branch it is written in.
+#define TVL_SHARED_STEP(Q, W)                                                                          \
+        {                                                                                              \
+            if ((Q) % CS == 0) stage_load((s + (Q)) / CS + 2, (((Q) / CS) & 1) ? stb : sta); \
+            if (s + (Q) < ns) compute_step(((Q) / CS) & 1, (Q) % CS, W);                               \
+            load_w(s + (Q) + DEPTH < last ? s + (Q) + DEPTH : last, W);                                \
+            if ((Q) % CS == CS - 1) {                                                                 \
+                stage_store((((Q) / CS) & 1) ^ 1, (((Q) / CS) & 1) ? sta : stb);                       \
+                __syncthreads();                                                                       \
+            }                                                                                          \
+        }
+        for (int s = 0; s < ns; s += DEPTH) {
+            TVL_SHARED_STEP(0, w0)
+            TVL_SHARED_STEP(1, w1)
+            TVL_SHARED_STEP(2, w2)
+            TVL_SHARED_STEP(3, w3)
+        }
+#undef TVL_SHARED_STEP
+    }
+
+    if constexpr (SPLIT) {
+        float* mine = slab + (int64_t)blockIdx.y * ((int64_t)m * n);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int gm = 16 * i + c, cn = n0 + 16 * t + 4 * g;
+                if (gm >= m) continue;
+                if ((n & 3) == 0 && cn + 4 <= n) {
+                    *reinterpret_cast<float4*>(mine + (int64_t)gm * n + cn) = make_float4(acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (cn + e < n) mine[(int64_t)gm * n + cn + e] = acc[i][t][e];
+                }
+            }
+    } else {
+        const float cl = fabsf(clip);
+        const bool has_bias = bias != nullptr;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+                rows_store_fragment(acc[i][t], 16 * i + c, n0 + 16 * t + 4 * g, m, n, scale, bias, has_bias, act, cl, act_begin, y, y_dtype, ld_y);
+    }
+}
+
+struct SharedPlan { int mr, cs, splits, per; double us; };   // per = steps of 256 k per split; us = modelled time
+
+// The k split, by a small cost model fitted to measurements: 0.65 / 1.0 / 1.53 us per 256-deep step of one workgroup at 16 / 32 /
+// 64 rows, the grid running in ceil(workgroups / CUs) rounds of `per` steps, a few us of launch, prologue and slab reduce.  (32
+// channels per wave - half the LDS reads per weight - measured 4 % faster at 32 and 64 rows x 16384 x 16384 and slower or equal
+// everywhere else: not built.)  TVL_ROWS_SHARED=<splits> pins the split, a negative value turns the kernel off (tuning).
+static SharedPlan plan_rows_shared(int64_t m, int64_t n, int64_t k, size_t workspace_bytes) {
+    static const int force_splits = [] { const char* e = getenv("TVL_ROWS_SHARED"); return e ? atoi(e) : 0; }();
+    static const double step_us[3] = {0.65, 1.0, 1.53};
+    SharedPlan best;
+    best.mr = m <= 16 ? 1 : (m <= 32 ? 2 : 4);
+    best.cs = best.mr == 4 ? 1 : 2;
+    best.splits = 1; best.per = (int)(k / 256); best.us = 1e30;
+    const int64_t steps = k / 256;
+    const int cus = device_cu_count();
+    const int64_t by_ws = (int64_t)(workspace_bytes / ((size_t)m * n * sizeof(float)));
+    const int64_t max_s = steps / 4 > 0 ? steps / 4 : 1;             // at least 4 steps (1024 k) per workgroup
+    const int64_t nblk = ceil_div(n, 128);
+    for (int64_t s = 1; s <= max_s; ++s) {
+        if (force_splits > 0 && s != (force_splits < max_s ? force_splits : max_s)) continue;
+        if (s > 1 && s > by_ws) break;
+        const int64_t per = ceil_div(steps, s), splits = ceil_div(steps, per);
+        if (splits != s) continue;                                     // the same split under a smaller s
+        const int64_t rounds = ceil_div(nblk * splits, (int64_t)cus);
+        const double us = 4.0 + (splits > 1 ? 2.0 + 0.25 * splits : 0.0) + (double)rounds * (1.0 + per * step_us[best.mr == 1 ? 0 : (best.mr == 2 ? 1 : 2)]);
+        if (us < best.us) { best.us = us; best.splits = (int)splits; best.per = (int)per; }
+    }
+    return best;
+}
+
+size_t gemm_rows_shared_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+    if (m > 64 || k % 256 != 0) return 0;
+    const SharedPlan p = plan_rows_shared(m, n, k, (size_t)1 << 40);
+    return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
+}
+
+bool gemm_rows_shared_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                                const void* workspace, size_t workspace_bytes) {
+    static const int mode = [] { const char* e = getenv("TVL_ROWS_SHARED"); return e ? atoi(e) : 0; }();
+    static const bool any_size = [] { const char* e = getenv("TVL_ROWS_SHARED_ANY"); return e && atoi(e) != 0; }();   // tests: small shapes too
+    if (mode < 0) return false;
+    if (x_dtype != TVL_F16 && x_dtype != TVL_BF16) return false;
+    if (m < 3 || m > 64 || k <= 0 || k % 256 != 0) return false;   // one or two rows: the table-lookup kernel
+    if (!aligned(x, 16) || (ld_x * 2) % 16 != 0) return false;
+    if (!aligned(pw, 16) || ld_pw % 16 != 0) return false;
+    if (n > INT32_MAX - 512 || k > INT32_MAX) return false;
+    if (any_size) return true;
+    // Measured crossovers against the kernels above / the split-K tiles, in weights (n k): e.g. us at 16 rows 15.4 -> 9.4 at
+    // 14336 x 2048, 17.1 -> 10.7 at 4096 x 8192, 19.1 -> 12.8 at 8192^2, 39 -> 29 at 16384^2, but 8.5 -> 9.2 at 4096^2; at 48
+    // rows 42 -> 21 at 8192^2; at 64 rows the 64-row matrix-core tile keeps 8192^2 (20.5 against 22.5) and loses 16384^2 (60 -> 52).
+    const double weights = (double)n * (double)k;
+    const double need = m <= 16 ? (k >= 8192 ? 1.5e7 : 2.0e7) : (m <= 32 ? 2.5e7 : (m <= 48 ? 3.0e7 : 2.0e8));
+    if (weights < need) return false;
+    const SharedPlan p = plan_rows_shared(m, n, k, (workspace && aligned(workspace, 16)) ? workspace_bytes : 0);
+    // without the workspace for its k split the grid would underfill the chip: leave the shape to the other kernels
+    return p.splits * ceil_div(n, 128) * 2 >= device_cu_count();
+}
+
+template <typename TX, int MR, int CS>
+static int launch_shared_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
+                             const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, const SharedPlan& p, float* slab,
+                             hipStream_t st) {
+    const size_t lds_bytes = (size_t)2 * CS * MR * 8 * 65 * 16;
+    constexpr int CT = 1;
+    const dim3 grid((unsigned)ceil_div(n, 128 * CT), (unsigned)p.splits), block(512);
+    if (p.splits > 1) {
+        auto kern = gemm_rows_shared_kernel<TX, MR, CT, CS, true>;
+        if (int rc = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc != TVL_OK) return rc;
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y,
+                           p.per, slab);
+        TVL_LAUNCH_CHECK();
+        return launch_splitk_reduce(slab, p.splits, m, n, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+    }
+    auto kern = gemm_rows_shared_kernel<TX, MR, CT, CS, false>;
+    if (int rc = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc != TVL_OK) return rc;
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, 0,
+                       (float*)nullptr);
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+template <typename TX>
+static int launch_shared_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
+                           const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, const SharedPlan& p, float* slab,
+                           hipStream_t st) {
+    if (p.mr == 1) return launch_shared_cfg<TX, 1, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, p, slab, st);
+    if (p.mr == 2) return launch_shared_cfg<TX, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, p, slab, st);
+    return launch_shared_cfg<TX, 4, 1>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, p, slab, st);
+}
+
+int launch_gemm_rows_shared(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                            const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y,
+                            void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (y_dtype != TVL_F32 && y_dtype != TVL_F16 && y_dtype != TVL_BF16) {
+        set_error("ternary_matmul: unsupported output dtype %d", y_dtype);
+        return TVL_ERR_INVALID;
+    }
+    const bool ws_ok = workspace != nullptr && aligned(workspace, 16);
+    const SharedPlan p = plan_rows_shared(m, n, k, ws_ok ? workspace_bytes : 0);
+    float* slab = reinterpret_cast<float*>(workspace);
+    if (x_dtype == TVL_F16)
+        return launch_shared_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, p, slab, st);
+    return launch_shared_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, p, slab, st);
 }
 
 }  // namespace tvl

@@ -135,8 +135,9 @@ static size_t aligned_workspace_bytes(int x_dtype, int64_t m, int64_t n, int64_t
     const size_t a = gemm_mfma_workspace_bytes(TVL_F16, m, n, k);
     const size_t b = (m <= 32 && k % 256 == 0) ? gemm_skinny_workspace_bytes(m, n, k) : 0;
     const size_t c = (m <= 16 && k % 256 == 0) ? gemm_stream_workspace_bytes(m, n, k) : 0;
-    const size_t ab = a > b ? a : b;
-    return ab > c ? ab : c;
+    const size_t d = (m <= 64 && k % 256 == 0) ? gemm_rows_shared_workspace_bytes(m, n, k) : 0;
+    const size_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 
 static size_t pad_route_bytes(int x_dtype, int64_t m, int64_t n, int64_t k) {
@@ -155,6 +156,8 @@ size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k) { ret
 static int dispatch_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
                            const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y,
                            void* workspace, size_t workspace_bytes, hipStream_t st, bool allow_pad) {
+    if (gemm_rows_shared_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
+        return launch_gemm_rows_shared(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     if (gemm_rows_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
         return launch_gemm_rows(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
     if (gemv_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))

@@ -55,6 +55,14 @@ bool gemm_rows_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64
 int launch_gemm_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
                      const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
 
+// gemm_rows.hip, larger layers: 3 .. 64 rows, the activations shared through LDS by 8 waves, k split into float32 slabs at `workspace`
+bool gemm_rows_shared_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                                const void* workspace, size_t workspace_bytes);
+int launch_gemm_rows_shared(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                            const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y,
+                            void* workspace, size_t workspace_bytes, hipStream_t st);
+size_t gemm_rows_shared_workspace_bytes(int64_t m, int64_t n, int64_t k);
+
 // gemm_skinny.hip
 bool gemm_skinny_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw);
 int launch_gemm_skinny(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,

@@ -134,3 +134,38 @@ def test_every_tile_plan_is_exact_when_pinned(plan):
                          capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert out.stdout.count(": ok") == 6 * len(shapes)
+
+
+@pytest.mark.parametrize("splits", ["0", "1", "3"])
+def test_shared_activation_rows_kernel_on_small_shapes(splits):
+    """The few-row kernel for large layers (8 waves share the activations through LDS, k split into slabs) is chosen by layer size,
+    so the ragged small shapes of the other tests never reach it.  Here a child process lifts the size rule
+    (TVL_ROWS_SHARED_ANY=1) and pins the k split (TVL_ROWS_SHARED: 0 = the planner's own): 3 .. 64 rows over the three row-block
+    variants, channel counts that are not multiples of 16 or 128, 1 .. 16 steps of 256, every dtype pair, bias, the activation
+    from a channel on, over-wide packed rows with code 3 (a multiple of 16 bytes wider, so the bf16 cases keep the 16-byte row
+    alignment the kernel needs), against the CPU oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = ["3,16,256", "5,300,1024", "16,130,4096", "17,257,1280", "32,128,2048", "33,200,768", "64,500,2304"]
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_plan.py"), *shapes],
+                         env=dict(os.environ, TVL_ROWS_SHARED_ANY="1", TVL_ROWS_SHARED=splits, CHECK_EXTRA="0,16,32"), capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert out.stdout.count(": ok") == 6 * len(shapes)
+
+
+@pytest.mark.parametrize("m,n,k,xdt", [(16, 8192, 8192, torch.float16), (24, 4096, 8192, torch.bfloat16), (48, 8192, 4096, torch.float16),
+                                       (9, 14336, 2048, torch.bfloat16)])
+def test_few_rows_on_large_layers_at_size(ops, dev, c_oracle, m, n, k, xdt):
+    """Decode batches on layers of 29 .. 67 million weights (where the shared-activation kernel is the library's own choice):
+    grid activations, so the float32 sums are exact and the product must equal the C oracle bit for bit."""
+    rng = np.random.default_rng(m * 7 + n)
+    x = rng.integers(-64, 65, size=(m, k)).astype(np.float32) / 64.0
+    pw = rng.integers(0, 171, size=(n, k // 4)).astype(np.uint8)
+    scale = (rng.integers(1, 9, size=(n,)) / 8.0).astype(np.float32)
+    bias = (rng.integers(-16, 17, size=(n,)) / 8.0).astype(np.float32)
+    want = c_oracle(x, pw, scale, bias, 1e6)
+    got = ops.ternary_matmul(torch.from_numpy(x).to(dev).to(xdt), torch.from_numpy(pw).to(dev), torch.from_numpy(scale).to(dev),
+                             torch.from_numpy(bias).to(dev), 1e6, out_dtype=torch.float32)
+    assert np.array_equal(got.cpu().numpy(), want)

@@ -18,6 +18,7 @@ ops = tv.custom_ops_mod
 dev = torch.device("cuda:0")
 shapes = [tuple(int(a) for a in s.split(",")) for s in sys.argv[1:]] or [(300, 500, 512), (129, 257, 64), (1000, 130, 1280), (256, 384, 192)]
 rng = np.random.default_rng(99)
+EXTRA = [int(a) for a in os.environ.get("CHECK_EXTRA", "0,8,16").split(",")]   # bytes appended to every packed row, per case % 3
 bad = 0
 for (m, n, k) in shapes:
     for case in range(6):
@@ -25,7 +26,7 @@ for (m, n, k) in shapes:
         ydt = [torch.float32, xdt][case % 2]
         has_bias, gelu = case % 2 == 0, case == 4
         act_begin = n // 3 if gelu else 0
-        extra = [0, 8, 16][case % 3]
+        extra = EXTRA[case % 3]
         x = rng.integers(-64, 65, size=(m, k)).astype(np.float32) / 64.0
         pw = rng.integers(0, 256, size=(n, k // 4 + extra)).astype(np.uint8)
         scale = (rng.integers(1, 9, size=(n,)) / 8.0).astype(np.float32) * (0.03125 if gelu else 1.0)
