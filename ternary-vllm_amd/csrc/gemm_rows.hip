@@ -229,60 +229,70 @@ int launch_gemm_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t l
 // ---- small layers, one launch, the activations staged once -------------------------------------------------------------------
 //
 // gemm_rows_kernel's fragment loads take 16 bytes per lane out of 64 different cache lines per instruction; at 16 x 4096 x 4096
-// those look-ups are about half of its 8.4 us.  When all of x fits in LDS (16 rows x k <= 4096, 32 rows x k <= 2048) the
-// workgroup - 8 waves on 16 channels, k split 8 ways - first brings it in with whole-cache-line loads (one 16-byte piece per
-// thread and 256-deep step, all steps in flight at once; written in the padded fragment layout of gemm_rows_shared_kernel), its
-// weight loads - issued AFTER the activation loads, so that waiting for the latter leaves them in flight - arriving meanwhile.
-// Then every wave multiplies its steps out of LDS and the partial sums are added through LDS in wave order as above.
-template <typename TX, int MR, int SPW>   // SPW: steps per wave (k <= 256 * 8 * SPW)
+// those look-ups are about half of its 8.4 us.  When x fits in LDS (16 rows x k <= 4096; 32 rows x k <= 2048, or k <= 4096 in two
+// phases) the workgroup - 8 waves on 16 channels, k split 8 ways - first brings it in with whole-cache-line loads (one 16-byte
+// piece per thread and 256-deep step, all steps of a phase in flight at once; written in the padded fragment layout of
+// gemm_rows_shared_kernel), its weight loads - issued AFTER the activation loads, so that waiting for the latter leaves them in
+// flight - arriving meanwhile.  Then every wave multiplies its steps out of LDS (the second phase's activations travelling in
+// registers meanwhile) and the partial sums are added through LDS in wave order as above.
+template <typename TX, int MR, int SPW, int PH>   // SPW: steps per wave and phase; PH: phases (k <= 256 * 8 * SPW * PH)
 __global__ void __launch_bounds__(512)
 gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
                         const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act, int act_begin, void* __restrict__ y,
                         int y_dtype, int64_t ld_y) {
-    constexpr int WAVES = 8, FS = 65, IMG = 8 * FS, MAXS = WAVES * SPW;
+    constexpr int WAVES = 8, FS = 65, IMG = 8 * FS, PS = WAVES * SPW;   // PS: steps per phase
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint4* xbuf = reinterpret_cast<uint4*>(lds_raw);                 // [steps][MR][8 fragments][FS]
+    uint4* xbuf = reinterpret_cast<uint4*>(lds_raw);                 // [steps of one phase][MR][8 fragments][FS]
     __shared__ floatx4 red[WAVES][MR][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int total = k / 256;
-    const int base = total / WAVES, rem = total % WAVES;
-    const int steps = base + (wave < rem ? 1 : 0);                    // this wave's share of the k steps (<= SPW)
-    const int s0 = wave * base + (wave < rem ? wave : rem);
+    const int nph = (total + PS - 1) / PS;                            // phases this k needs (<= PH)
 
-    // ---- activation loads: thread t = (row t >> 5 of each 16-row block, piece t & 31) of every step
+    // ---- activation loads: thread t = (row t >> 5 of each 16-row block, piece t & 31) of every step of a phase
     const int st_row = threadIdx.x >> 5, st_p = threadIdx.x & 31;
-    nts_u32x4 st[MAXS][MR];
+    const uint4* xsrc[MR];
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
         int gm = 16 * i + st_row;
         gm = gm < m ? gm : m - 1;
-        const uint4* src = reinterpret_cast<const uint4*>(x + (int64_t)gm * ld_x + 8 * st_p);
-#pragma unroll
-        for (int s = 0; s < MAXS; ++s) {
-            const int ss = s < total ? s : total - 1;                // past the end: the last step again (stored, never read)
-            st[s][i] = *reinterpret_cast<const nts_u32x4*>(src + (int64_t)ss * 32);
-        }
+        xsrc[i] = reinterpret_cast<const uint4*>(x + (int64_t)gm * ld_x + 8 * st_p);
     }
-    // ---- weight loads of all of this wave's steps (past its share: its last step again, never used)
+    nts_u32x4 st[PS][MR];
+    auto load_phase = [&](int ph) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int s = 0; s < PS; ++s) {
+                int ss = ph * PS + s;
+                ss = ss < total ? ss : total - 1;                    // past the end: the last step again (never read back)
+                st[s][i] = *reinterpret_cast<const nts_u32x4*>(xsrc[i] + (int64_t)ss * 32);
+            }
+    };
+    const int st_dst = (st_p & 7) * FS + (st_p >> 3) * 16 + st_row;
+    auto store_phase = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < PS; ++s)
+#pragma unroll
+            for (int i = 0; i < MR; ++i) *reinterpret_cast<nts_u32x4*>(xbuf + (s * MR + i) * IMG + st_dst) = st[s][i];
+    };
+    load_phase(0);
+    // ---- weight loads of all of this wave's steps: step ph * PS + wave * SPW + q (past the end: the last step again, never used)
     int gn = n0 + c;
     gn = gn < n ? gn : n - 1;
     const uint4* wp = reinterpret_cast<const uint4*>(pw + (int64_t)gn * ld_pw + 16 * g);
-    uint4 w[SPW];
+    uint4 w[PH][SPW];
 #pragma unroll
-    for (int q = 0; q < SPW; ++q) {
-        int s = s0 + (q < steps ? q : (steps > 0 ? steps - 1 : 0));
-        s = s < total ? s : total - 1;
-        const nts_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nts_u32x4*>(wp + (int64_t)s * 4));
-        w[q] = make_uint4(v[0], v[1], v[2], v[3]);
-    }
-    const int st_dst = (st_p & 7) * FS + (st_p >> 3) * 16 + st_row;
+    for (int ph = 0; ph < PH; ++ph)
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s)
-#pragma unroll
-        for (int i = 0; i < MR; ++i)
-            if (s < total) *reinterpret_cast<nts_u32x4*>(xbuf + (s * MR + i) * IMG + st_dst) = st[s][i];
+        for (int q = 0; q < SPW; ++q) {
+            int s = ph * PS + wave * SPW + q;
+            s = s < total ? s : total - 1;
+            const nts_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nts_u32x4*>(wp + (int64_t)s * 4));
+            w[ph][q] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    store_phase();
     __syncthreads();
 
     floatx4 acc[MR];
@@ -290,20 +300,32 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
     for (int i = 0; i < MR; ++i) acc[i] = (floatx4){0.f, 0.f, 0.f, 0.f};
     const DecodeConsts dc = make_decode_consts();
 #pragma unroll
-    for (int q = 0; q < SPW; ++q) {
-        if (q < steps) {
-            const uint4* img = xbuf + (s0 + q) * MR * IMG + lane;
-            uint4 xf[8][MR];
+    for (int ph = 0; ph < PH; ++ph) {
+        if (ph < nph) {
+            if (ph + 1 < PH && ph + 1 < nph) load_phase(ph + 1);      // the next phase's activations travel while this one is multiplied
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int q = 0; q < SPW; ++q) {
+                if (ph * PS + wave * SPW + q < total) {
+                    const uint4* img = xbuf + (wave * SPW + q) * MR * IMG + lane;
+                    uint4 xf[8][MR];
 #pragma unroll
-                for (int i = 0; i < MR; ++i) xf[j][i] = img[i * IMG + j * FS];
+                    for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t d = (j >> 1) == 0 ? w[q].x : (j >> 1) == 1 ? w[q].y : (j >> 1) == 2 ? w[q].z : w[q].w;
-                const uint4 a = (j & 1) ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc);
+                        for (int i = 0; i < MR; ++i) xf[j][i] = img[i * IMG + j * FS];
 #pragma unroll
-                for (int i = 0; i < MR; ++i) acc[i] = mfma16<TX>(a, xf[j][i], acc[i]);
+                    for (int j = 0; j < 8; ++j) {
+                        const uint4 wq = w[ph][q];
+                        const uint32_t d = (j >> 1) == 0 ? wq.x : (j >> 1) == 1 ? wq.y : (j >> 1) == 2 ? wq.z : wq.w;
+                        const uint4 a = (j & 1) ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc);
+#pragma unroll
+                        for (int i = 0; i < MR; ++i) acc[i] = mfma16<TX>(a, xf[j][i], acc[i]);
+                    }
+                }
+            }
+            if (ph + 1 < PH && ph + 1 < nph) {
+                __syncthreads();                                      // everyone has read this phase's image
+                store_phase();
+                __syncthreads();
             }
         }
     }
@@ -320,26 +342,12 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
     }
 }
 
-// x must fit in LDS; 3 or 4 rows and very small layers stay with gemm_rows_kernel (5.3 against 5.6 us at 3 x 4096^2, 3.2 against
-// 3.4 at 16 x 512^2); measured otherwise (us): 16 x 4096^2 8.4 -> 6.25, 16 x 2048^2 5.1 -> 3.7, 16 x 6144 x 2048 9.3 -> 5.8,
-// 8 x 4096^2 6.4 -> 5.7, 32 x 2048^2 8.0 -> 5.35.  TVL_ROWS_STAGED=0 turns it off (tuning), 2 lifts the size rules (tests).
-static bool rows_use_staged(int64_t m, int64_t n, int64_t k) {
-    static const int mode = [] { const char* e = getenv("TVL_ROWS_STAGED"); return e ? atoi(e) : 1; }();   // 2: whatever fits (tests)
-    if (mode == 2) return m <= 16 ? k <= 4096 : k <= 2048;
-    if (mode == 0 || m < 5 || (double)n * (double)k < 1.0e6) return false;
-    if (m <= 16) return k <= 4096;   // (larger layers never get here: beyond 2e7 weights the shared-activation kernel takes them)
-    // 17 .. 32 rows: 133 KiB of LDS at k = 2048, one workgroup per compute unit - every further round of workgroups stages x again
-    // (32 x 4096 x 2048: 8.9 -> 5.8 us, but 32 x 11008 x 2048: 12.6 -> 13.8, 32 x 16384 x 1024: 10.3 -> 15.3)
-    if (k > 2048) return false;
-    const int64_t per_cu = k <= 1024 ? 2 : 1;
-    return 4 * ceil_div(n, 16) <= 5 * per_cu * (int64_t)device_cu_count();
-}
-
-template <typename TX, int MR, int SPW>
+template <typename TX, int MR, int SPW, int PH>
 static int launch_rows_staged_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                                   const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
-    const size_t lds_bytes = (size_t)(k / 256) * MR * 8 * 65 * 16;
-    auto kern = gemm_rows_staged_kernel<TX, MR, SPW>;
+    const int64_t steps = k / 256, phase_steps = steps < 8 * SPW ? steps : 8 * SPW;
+    const size_t lds_bytes = (size_t)phase_steps * MR * 8 * 65 * 16;
+    auto kern = gemm_rows_staged_kernel<TX, MR, SPW, PH>;
     if (int rc = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc != TVL_OK) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(n, 16)), dim3(512), lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act,
                        act_begin, y, y_dtype, ld_y);
@@ -350,11 +358,30 @@ static int launch_rows_staged_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_
 template <typename TX>
 static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                                 const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
+#define TVL_STAGED(MR, SPW, PH) \
+    return launch_rows_staged_cfg<TX, MR, SPW, PH>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st)
     if (m <= 16) {
-        if (k <= 2048) return launch_rows_staged_cfg<TX, 1, 1>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
-        return launch_rows_staged_cfg<TX, 1, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+        if (k <= 2048) TVL_STAGED(1, 1, 1);
+        TVL_STAGED(1, 2, 1);
     }
-    return launch_rows_staged_cfg<TX, 2, 1>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+    if (k <= 2048) TVL_STAGED(2, 1, 1);
+    TVL_STAGED(2, 1, 2);
+#undef TVL_STAGED
+}
+
+// x must fit in LDS; 3 or 4 rows and very small layers stay with gemm_rows_kernel (5.3 against 5.6 us at 3 x 4096^2, 3.2 against
+// 3.4 at 16 x 512^2); measured otherwise (us): 16 x 4096^2 8.4 -> 6.25, 16 x 2048^2 5.1 -> 3.7, 16 x 6144 x 2048 9.3 -> 5.8,
+// 8 x 4096^2 6.4 -> 5.7, 32 x 2048^2 8.0 -> 5.35.  TVL_ROWS_STAGED=0 turns it off (tuning), 2 lifts the size rules (tests).
+static bool rows_use_staged(int64_t m, int64_t n, int64_t k) {
+    static const int mode = [] { const char* e = getenv("TVL_ROWS_STAGED"); return e ? atoi(e) : 1; }();   // 2: whatever fits (tests)
+    if (mode == 2) return k <= 4096;
+    if (mode == 0 || m < 5 || (double)n * (double)k < 1.0e6) return false;
+    if (m <= 16) return k <= 4096;   // (larger layers never get here: beyond 2e7 weights the shared-activation kernel takes them)
+    // 17 .. 32 rows: 133 KiB of LDS from k = 2048 on (k = 4096 in two phases), one workgroup per compute unit - a second round of
+    // workgroups stages x again (32 x 4096 x 4096: 10.8 -> 8.4 us, but 32 x 5120 x 4096: 12.3 -> 14.3, 32 x 16384 x 1024: 10.3 -> 15.3)
+    if (k > 4096) return false;
+    const int64_t per_cu = k <= 1024 ? 2 : 1;
+    return ceil_div(n, 16) <= per_cu * (int64_t)device_cu_count();
 }
 
 // ---- larger layers, up to 64 rows: the weight stream of 8 waves shares one copy of the activations in LDS --------------------
