@@ -226,6 +226,25 @@ int launch_gemm_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t l
     return launch_rows_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
 }
 
+// LDS of one workgroup: the image of one phase (at most 8 * SPW steps), reused for the partial sums
+static size_t rows_staged_lds_bytes(int mr, int ct, int64_t k) {
+    const int64_t steps = k / 256, spw = (mr == 1 && k > 2048) ? 2 : 1, phase_steps = steps < 8 * spw ? steps : 8 * spw;
+    const size_t image = (size_t)phase_steps * mr * 8 * 65 * 16, sums = (size_t)8 * mr * ct * 64 * 16;
+    return image > sums ? image : sums;
+}
+// 16-channel tiles per workgroup: 1 while one round of workgroups covers n, else 2 or 4 (two-phase form: 1)
+static int rows_staged_tiles(int64_t m, int64_t n, int64_t k) {
+    const int mr = m <= 16 ? 1 : 2;
+    if (mr == 2 && k > 2048) return 1;
+    const int max_ct = mr == 1 ? 4 : 2;
+    for (int ct = 1; ct < max_ct; ct *= 2) {
+        int64_t per_cu = (int64_t)(160 * 1024) / (int64_t)(rows_staged_lds_bytes(mr, ct, k) + 1024);
+        per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+        if (ceil_div(n, 16 * ct) <= per_cu * device_cu_count()) return ct;
+    }
+    return max_ct;
+}
+
 // ---- small layers, one launch, the activations staged once -------------------------------------------------------------------
 //
 // gemm_rows_kernel's fragment loads take 16 bytes per lane out of 64 different cache lines per instruction; at 16 x 4096 x 4096
@@ -235,18 +254,18 @@ int launch_gemm_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t l
 // gemm_rows_shared_kernel), its weight loads - issued AFTER the activation loads, so that waiting for the latter leaves them in
 // flight - arriving meanwhile.  Then every wave multiplies its steps out of LDS (the second phase's activations travelling in
 // registers meanwhile) and the partial sums are added through LDS in wave order as above.
-template <typename TX, int MR, int SPW, int PH>   // SPW: steps per wave and phase; PH: phases (k <= 256 * 8 * SPW * PH)
+template <typename TX, int MR, int CT, int SPW, int PH>   // CT: 16-channel tiles per workgroup; SPW: steps per wave and phase; PH: phases
 __global__ void __launch_bounds__(512)
 gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
                         const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act, int act_begin, void* __restrict__ y,
                         int y_dtype, int64_t ld_y) {
-    constexpr int WAVES = 8, FS = 65, IMG = 8 * FS, PS = WAVES * SPW;   // PS: steps per phase
+    constexpr int WAVES = 8, FS = 65, IMG = 8 * FS, PS = WAVES * SPW;   // PS: steps per phase (k <= 256 * PS * PH)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4* xbuf = reinterpret_cast<uint4*>(lds_raw);                 // [steps of one phase][MR][8 fragments][FS]
-    __shared__ floatx4 red[WAVES][MR][64];
+    floatx4* red = reinterpret_cast<floatx4*>(lds_raw);              // [WAVES][MR * CT][64], over the image once it has been read
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * (16 * CT);
     const int total = k / 256;
     const int nph = (total + PS - 1) / PS;                            // phases this k needs (<= PH)
 
@@ -279,25 +298,30 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
     };
     load_phase(0);
     // ---- weight loads of all of this wave's steps: step ph * PS + wave * SPW + q (past the end: the last step again, never used)
-    int gn = n0 + c;
-    gn = gn < n ? gn : n - 1;
-    const uint4* wp = reinterpret_cast<const uint4*>(pw + (int64_t)gn * ld_pw + 16 * g);
-    uint4 w[PH][SPW];
+    uint4 w[PH][SPW][CT];
 #pragma unroll
-    for (int ph = 0; ph < PH; ++ph)
+    for (int t = 0; t < CT; ++t) {
+        int gn = n0 + 16 * t + c;
+        gn = gn < n ? gn : n - 1;
+        const uint4* wp = reinterpret_cast<const uint4*>(pw + (int64_t)gn * ld_pw + 16 * g);
 #pragma unroll
-        for (int q = 0; q < SPW; ++q) {
-            int s = ph * PS + wave * SPW + q;
-            s = s < total ? s : total - 1;
-            const nts_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nts_u32x4*>(wp + (int64_t)s * 4));
-            w[ph][q] = make_uint4(v[0], v[1], v[2], v[3]);
-        }
+        for (int ph = 0; ph < PH; ++ph)
+#pragma unroll
+            for (int q = 0; q < SPW; ++q) {
+                int s = ph * PS + wave * SPW + q;
+                s = s < total ? s : total - 1;
+                const nts_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nts_u32x4*>(wp + (int64_t)s * 4));
+                w[ph][q][t] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+    }
     store_phase();
     __syncthreads();
 
-    floatx4 acc[MR];
+    floatx4 acc[MR][CT];
 #pragma unroll
-    for (int i = 0; i < MR; ++i) acc[i] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[i][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
     const DecodeConsts dc = make_decode_consts();
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph) {
@@ -313,13 +337,15 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
 #pragma unroll
                         for (int i = 0; i < MR; ++i) xf[j][i] = img[i * IMG + j * FS];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint4 wq = w[ph][q];
-                        const uint32_t d = (j >> 1) == 0 ? wq.x : (j >> 1) == 1 ? wq.y : (j >> 1) == 2 ? wq.z : wq.w;
-                        const uint4 a = (j & 1) ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc);
+                    for (int j = 0; j < 8; ++j)
 #pragma unroll
-                        for (int i = 0; i < MR; ++i) acc[i] = mfma16<TX>(a, xf[j][i], acc[i]);
-                    }
+                        for (int t = 0; t < CT; ++t) {
+                            const uint4 wq = w[ph][q][t];
+                            const uint32_t d = (j >> 1) == 0 ? wq.x : (j >> 1) == 1 ? wq.y : (j >> 1) == 2 ? wq.z : wq.w;
+                            const uint4 a = (j & 1) ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc);
+#pragma unroll
+                            for (int i = 0; i < MR; ++i) acc[i][t] = mfma16<TX>(a, xf[j][i], acc[i][t]);
+                        }
                 }
             }
             if (ph + 1 < PH && ph + 1 < nph) {
@@ -329,28 +355,31 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
             }
         }
     }
+    __syncthreads();                                                  // the image has been read: its memory now takes the partial sums
 #pragma unroll
-    for (int i = 0; i < MR; ++i) red[wave][i][lane] = acc[i];
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) red[(wave * MR * CT + i * CT + t) * 64 + lane] = acc[i][t];
     __syncthreads();
     const float cl = fabsf(clip);
     const bool has_bias = bias != nullptr;
-    for (int i = wave; i < MR; i += WAVES) {
-        floatx4 s = red[0][i][lane];
+    for (int f = wave; f < MR * CT; f += WAVES) {
+        const int i = f / CT, t = f % CT;
+        floatx4 s = red[f * 64 + lane];
 #pragma unroll
-        for (int ww = 1; ww < WAVES; ++ww) s += red[ww][i][lane];
-        rows_store_fragment(s, 16 * i + c, n0 + 4 * g, m, n, scale, bias, has_bias, act, cl, act_begin, y, y_dtype, ld_y);
+        for (int ww = 1; ww < WAVES; ++ww) s += red[(ww * MR * CT + f) * 64 + lane];
+        rows_store_fragment(s, 16 * i + c, n0 + 16 * t + 4 * g, m, n, scale, bias, has_bias, act, cl, act_begin, y, y_dtype, ld_y);
     }
 }
 
-template <typename TX, int MR, int SPW, int PH>
+template <typename TX, int MR, int CT, int SPW, int PH>
 static int launch_rows_staged_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                                   const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
-    const int64_t steps = k / 256, phase_steps = steps < 8 * SPW ? steps : 8 * SPW;
-    const size_t lds_bytes = (size_t)phase_steps * MR * 8 * 65 * 16;
-    auto kern = gemm_rows_staged_kernel<TX, MR, SPW, PH>;
+    const size_t lds_bytes = rows_staged_lds_bytes(MR, CT, k);
+    auto kern = gemm_rows_staged_kernel<TX, MR, CT, SPW, PH>;
     if (int rc = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc != TVL_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(n, 16)), dim3(512), lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, act,
-                       act_begin, y, y_dtype, ld_y);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(n, 16 * CT)), dim3(512), lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip,
+                       act, act_begin, y, y_dtype, ld_y);
     TVL_LAUNCH_CHECK();
     return TVL_OK;
 }
@@ -358,30 +387,45 @@ static int launch_rows_staged_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_
 template <typename TX>
 static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                                 const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
-#define TVL_STAGED(MR, SPW, PH) \
-    return launch_rows_staged_cfg<TX, MR, SPW, PH>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st)
+    const int ct = rows_staged_tiles(m, n, k);
+#define TVL_STAGED(MR, CT, SPW, PH) \
+    return launch_rows_staged_cfg<TX, MR, CT, SPW, PH>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st)
+#define TVL_STAGED_CT(MR, SPW, PH)                   \
+    do {                                             \
+        if (ct == 1) TVL_STAGED(MR, 1, SPW, PH);     \
+        if (ct == 2) TVL_STAGED(MR, 2, SPW, PH);     \
+        TVL_STAGED(MR, 4, SPW, PH);                  \
+    } while (0)
     if (m <= 16) {
-        if (k <= 2048) TVL_STAGED(1, 1, 1);
-        TVL_STAGED(1, 2, 1);
+        if (k <= 2048) TVL_STAGED_CT(1, 1, 1);
+        TVL_STAGED_CT(1, 2, 1);
     }
-    if (k <= 2048) TVL_STAGED(2, 1, 1);
-    TVL_STAGED(2, 1, 2);
+    if (k <= 2048) { if (ct == 1) TVL_STAGED(2, 1, 1, 1); TVL_STAGED(2, 2, 1, 1); }
+    TVL_STAGED(2, 1, 1, 2);
+#undef TVL_STAGED_CT
 #undef TVL_STAGED
 }
 
-// x must fit in LDS; 3 or 4 rows and very small layers stay with gemm_rows_kernel (5.3 against 5.6 us at 3 x 4096^2, 3.2 against
-// 3.4 at 16 x 512^2); measured otherwise (us): 16 x 4096^2 8.4 -> 6.25, 16 x 2048^2 5.1 -> 3.7, 16 x 6144 x 2048 9.3 -> 5.8,
-// 8 x 4096^2 6.4 -> 5.7, 32 x 2048^2 8.0 -> 5.35.  TVL_ROWS_STAGED=0 turns it off (tuning), 2 lifts the size rules (tests).
+// x must fit in LDS (k <= 4096; 17 .. 32 rows above k = 2048: two phases) and the grid should run in one round: every further
+// round of workgroups stages x again (16 x 28672 x 4096, two rounds: 19.6 us against 14.2 for the shared-activation kernel), so a
+// workgroup takes 2 or 4 channel tiles on wide layers.  3 or 4 rows and very small layers stay with gemm_rows_kernel (5.3 against 5.6
+// us at 3 x 4096^2, 3.2 against 3.4 at 16 x 512^2).  Measured otherwise (us, against the dispatch without this kernel):
+// 16 x 4096^2 8.4 -> 5.9, 16 x 2048^2 5.1 -> 3.7, 16 x 6144 x 2048 9.3 -> 5.8, 8 x 4096^2 6.4 -> 5.7, 32 x 2048^2 8.0 -> 5.35,
+// 32 x 4096^2 10.8 -> 8.4; against the shared-activation kernel 16 x 14336 x 2048 9.4 -> 6.8, 16 x 8192 x 4096 10.5 -> 7.9,
+// 32 x 8192 x 2048 10.4 -> 6.6, 16 x 14336 x 4096 11.7 -> 10.8, but 16 x 32000 x 1024 6.7 -> 7.5.
+// TVL_ROWS_STAGED=0 turns it off (tuning), 2 lifts the size rules (tests).
 static bool rows_use_staged(int64_t m, int64_t n, int64_t k) {
     static const int mode = [] { const char* e = getenv("TVL_ROWS_STAGED"); return e ? atoi(e) : 1; }();   // 2: whatever fits (tests)
-    if (mode == 2) return k <= 4096;
-    if (mode == 0 || m < 5 || (double)n * (double)k < 1.0e6) return false;
-    if (m <= 16) return k <= 4096;   // (larger layers never get here: beyond 2e7 weights the shared-activation kernel takes them)
-    // 17 .. 32 rows: 133 KiB of LDS from k = 2048 on (k = 4096 in two phases), one workgroup per compute unit - a second round of
-    // workgroups stages x again (32 x 4096 x 4096: 10.8 -> 8.4 us, but 32 x 5120 x 4096: 12.3 -> 14.3, 32 x 16384 x 1024: 10.3 -> 15.3)
-    if (k > 4096) return false;
-    const int64_t per_cu = k <= 1024 ? 2 : 1;
-    return ceil_div(n, 16) <= per_cu * (int64_t)device_cu_count();
+    if (k > 4096 || m > 32) return false;
+    if (mode == 2) return true;
+    const double weights = (double)n * (double)k;
+    if (mode == 0 || m < 5 || weights < 1.0e6) return false;
+    if (k <= 1024 && weights >= 2.0e7) return false;
+    const int mr = m <= 16 ? 1 : 2, ct = rows_staged_tiles(m, n, k);
+    int64_t per_cu = (int64_t)(160 * 1024) / (int64_t)(rows_staged_lds_bytes(mr, ct, k) + 1024);
+    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    const int64_t rounds_allowed = (mr == 2 && k <= 2048) ? 2 : 1;   // at 17 .. 32 rows the alternatives are slower: two rounds still win
+    return ceil_div(n, 16 * ct) <= rounds_allowed * per_cu * (int64_t)device_cu_count();
 }
 
 // ---- larger layers, up to 64 rows: the weight stream of 8 waves shares one copy of the activations in LDS --------------------
@@ -619,6 +663,7 @@ bool gemm_rows_shared_supported(const void* x, int x_dtype, int64_t m, int64_t k
     if (!aligned(pw, 16) || ld_pw % 16 != 0) return false;
     if (n > INT32_MAX - 512 || k > INT32_MAX) return false;
     if (any_size) return true;
+    if (rows_use_staged(m, n, k)) return false;   // x fits in LDS and one round of workgroups covers n: the one-launch kernel above
     // Measured crossovers against the kernels above / the split-K tiles, in weights (n k): e.g. us at 16 rows 15.4 -> 9.4 at
     // 14336 x 2048, 17.1 -> 10.7 at 4096 x 8192, 19.1 -> 12.8 at 8192^2, 39 -> 29 at 16384^2, but 8.5 -> 9.2 at 4096^2; at 48
     // rows 42 -> 21 at 8192^2; at 64 rows the 64-row matrix-core tile keeps 8192^2 (20.5 against 22.5) and loses 16384^2 (60 -> 52).
