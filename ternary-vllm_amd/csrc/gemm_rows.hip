@@ -236,7 +236,7 @@ static size_t rows_staged_lds_bytes(int mr, int ct, int64_t k) {
 static int rows_staged_tiles(int64_t m, int64_t n, int64_t k) {
     const int mr = m <= 16 ? 1 : 2;
     if (mr == 2 && k > 2048) return 1;
-    const int max_ct = mr == 1 ? 4 : 2;
+    const int max_ct = mr == 1 ? (k > 4096 ? 2 : 4) : 2;   // (two phases with 4 tiles: 16 x 16384 x 8192 17.4 -> 17.8 us, not used)
     for (int ct = 1; ct < max_ct; ct *= 2) {
         int64_t per_cu = (int64_t)(160 * 1024) / (int64_t)(rows_staged_lds_bytes(mr, ct, k) + 1024);
         per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
@@ -248,7 +248,7 @@ static int rows_staged_tiles(int64_t m, int64_t n, int64_t k) {
 // ---- small layers, one launch, the activations staged once -------------------------------------------------------------------
 //
 // gemm_rows_kernel's fragment loads take 16 bytes per lane out of 64 different cache lines per instruction; at 16 x 4096 x 4096
-// those look-ups are about half of its 8.4 us.  When x fits in LDS (16 rows x k <= 4096; 32 rows x k <= 2048, or k <= 4096 in two
+// those look-ups are about half of its 8.4 us.  When x fits in LDS (16 rows x k <= 4096, 32 rows x k <= 2048; twice that k in two
 // phases) the workgroup - 8 waves on 16 channels, k split 8 ways - first brings it in with whole-cache-line loads (one 16-byte
 // piece per thread and 256-deep step, all steps of a phase in flight at once; written in the padded fragment layout of
 // gemm_rows_shared_kernel), its weight loads - issued AFTER the activation loads, so that waiting for the latter leaves them in
@@ -398,7 +398,8 @@ static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x,
     } while (0)
     if (m <= 16) {
         if (k <= 2048) TVL_STAGED_CT(1, 1, 1);
-        TVL_STAGED_CT(1, 2, 1);
+        if (k <= 4096) TVL_STAGED_CT(1, 2, 1);
+        TVL_STAGED_CT(1, 2, 2);
     }
     if (k <= 2048) { if (ct == 1) TVL_STAGED(2, 1, 1, 1); TVL_STAGED(2, 2, 1, 1); }
     TVL_STAGED(2, 1, 1, 2);
@@ -406,7 +407,7 @@ static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x,
 #undef TVL_STAGED
 }
 
-// x must fit in LDS (k <= 4096; 17 .. 32 rows above k = 2048: two phases) and the grid should run in one round: every further
+// x must fit in LDS in at most two phases (k <= 8192 up to 16 rows, k <= 4096 up to 32) and the grid should run in one round: every further
 // round of workgroups stages x again (16 x 28672 x 4096, two rounds: 19.6 us against 14.2 for the shared-activation kernel), so a
 // workgroup takes 2 or 4 channel tiles on wide layers.  3 or 4 rows and very small layers stay with gemm_rows_kernel (5.3 against 5.6
 // us at 3 x 4096^2, 3.2 against 3.4 at 16 x 512^2).  Measured otherwise (us, against the dispatch without this kernel):
@@ -416,7 +417,7 @@ static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x,
 // TVL_ROWS_STAGED=0 turns it off (tuning), 2 lifts the size rules (tests).
 static bool rows_use_staged(int64_t m, int64_t n, int64_t k) {
     static const int mode = [] { const char* e = getenv("TVL_ROWS_STAGED"); return e ? atoi(e) : 1; }();   // 2: whatever fits (tests)
-    if (k > 4096 || m > 32) return false;
+    if (m > 32 || k > (m <= 16 ? 8192 : 4096)) return false;
     if (mode == 2) return true;
     const double weights = (double)n * (double)k;
     if (mode == 0 || m < 5 || weights < 1.0e6) return false;

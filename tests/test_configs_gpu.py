@@ -181,7 +181,7 @@ def test_staged_rows_kernel_on_small_shapes():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     shapes = ["3,50,512", "5,300,1024", "9,33,256", "16,130,4096", "16,100,768", "12,257,2304", "17,257,1280", "32,128,2048", "25,40,256",
-              "32,128,4096", "20,100,2560", "16,20000,256", "8,40000,256", "20,5000,2048"]   # the last three: 2 / 4 / 2 channel tiles per workgroup
+              "32,128,4096", "20,100,2560", "16,130,8192", "7,300,5120", "16,20000,256", "8,40000,256", "20,5000,2048"]   # the last three: 2 / 4 / 2 channel tiles per workgroup
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_plan.py"), *shapes],
                          env=dict(os.environ, TVL_ROWS_STAGED="2", CHECK_EXTRA="0,16,32"), capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
