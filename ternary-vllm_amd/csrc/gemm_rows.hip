@@ -409,18 +409,18 @@ static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x,
 
 // x must fit in LDS in at most two phases (k <= 8192 up to 16 rows, k <= 4096 up to 32) and the grid should run in one round: every further
 // round of workgroups stages x again (16 x 28672 x 4096, two rounds: 19.6 us against 14.2 for the shared-activation kernel), so a
-// workgroup takes 2 or 4 channel tiles on wide layers.  3 or 4 rows and very small layers stay with gemm_rows_kernel (5.3 against 5.6
-// us at 3 x 4096^2, 3.2 against 3.4 at 16 x 512^2).  Measured otherwise (us, against the dispatch without this kernel):
+// workgroup takes 2 or 4 channel tiles on wide layers.  Very small layers stay with gemm_rows_kernel (3.2 against 3.4 us at
+// 16 x 512^2).  Measured otherwise (us, against the dispatch without this kernel):
 // 16 x 4096^2 8.4 -> 5.9, 16 x 2048^2 5.1 -> 3.7, 16 x 6144 x 2048 9.3 -> 5.8, 8 x 4096^2 6.4 -> 5.7, 32 x 2048^2 8.0 -> 5.35,
 // 32 x 4096^2 10.8 -> 8.4; against the shared-activation kernel 16 x 14336 x 2048 9.4 -> 6.8, 16 x 8192 x 4096 10.5 -> 7.9,
-// 32 x 8192 x 2048 10.4 -> 6.6, 16 x 14336 x 4096 11.7 -> 10.8, but 16 x 32000 x 1024 6.7 -> 7.5.
+// 32 x 8192 x 2048 10.4 -> 6.6, 16 x 14336 x 4096 11.7 -> 10.8, but 16 x 32000 x 1024 6.7 -> 7.5; 4 x 6144 x 2048 6.2 -> 5.0.
 // TVL_ROWS_STAGED=0 turns it off (tuning), 2 lifts the size rules (tests).
 static bool rows_use_staged(int64_t m, int64_t n, int64_t k) {
     static const int mode = [] { const char* e = getenv("TVL_ROWS_STAGED"); return e ? atoi(e) : 1; }();   // 2: whatever fits (tests)
     if (m > 32 || k > (m <= 16 ? 8192 : 4096)) return false;
     if (mode == 2) return true;
     const double weights = (double)n * (double)k;
-    if (mode == 0 || m < 5 || weights < 1.0e6) return false;
+    if (mode == 0 || m < 3 || weights < 1.0e6) return false;
     if (k <= 1024 && weights >= 2.0e7) return false;
     const int mr = m <= 16 ? 1 : 2, ct = rows_staged_tiles(m, n, k);
     int64_t per_cu = (int64_t)(160 * 1024) / (int64_t)(rows_staged_lds_bytes(mr, ct, k) + 1024);

@@ -34,8 +34,8 @@ def gemm_bytes(m, n, k, x_bytes=2, y_bytes=2):
 g = os.path.join(src, "gemm_4096_pmc_summary.txt")
 r = os.path.join(src, "rows_decode_pmc_summary.txt")
 f, w = means(r, "FETCH_SIZE"), means(r, "WRITE_SIZE")
-# order of the passes in profile_round2.sh step 4: rows 16x4096^2, shared 16x8192^2, shared 16x16384^2, gemv 1x16384^2, pack 4096^2
-names = [("gemm_rows_16x4096x4096_f16", gemm_bytes(16, 4096, 4096)), ("gemm_rows_shared_16x8192x8192_f16", gemm_bytes(16, 8192, 8192)),
+# order of the passes in profile_round2.sh step 4: staged 16x4096^2, shared 16x28672x4096, shared 16x16384^2, gemv 1x16384^2, pack 4096^2
+names = [("gemm_rows_staged_16x4096x4096_f16", gemm_bytes(16, 4096, 4096)), ("gemm_rows_shared_16x28672x4096_f16", gemm_bytes(16, 28672, 4096)),
          ("gemm_rows_shared_16x16384x16384_f16", gemm_bytes(16, 16384, 16384)), ("gemv_1x16384x16384_f16", gemm_bytes(1, 16384, 16384)),
          ("quantize_pack_4096x4096_f32", 4 * 4096 * 4096 + 4096 * 1024)]
 assert len(f) == len(names) and len(w) == len(names), (f, w)

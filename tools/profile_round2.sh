@@ -43,8 +43,8 @@ echo "mid counters done"
 # 4. few-row kernel and decode kernel traffic, arena pack traffic
 : > $O/rows_decode_pmc_summary.txt
 for grp in "FETCH_SIZE" "WRITE_SIZE"; do
-  pmc $O/rows_decode_pmc_summary.txt gemm_rows_kernel "$grp" -- $R/tools/run_shapes.py 16,4096,4096
-  pmc $O/rows_decode_pmc_summary.txt gemm_rows_shared_kernel "$grp" -- $R/tools/run_shapes.py 16,8192,8192
+  pmc $O/rows_decode_pmc_summary.txt gemm_rows_staged_kernel "$grp" -- $R/tools/run_shapes.py 16,4096,4096
+  pmc $O/rows_decode_pmc_summary.txt gemm_rows_shared_kernel "$grp" -- $R/tools/run_shapes.py 16,28672,4096
   pmc $O/rows_decode_pmc_summary.txt gemm_rows_shared_kernel "$grp" -- $R/tools/run_shapes.py 16,16384,16384
   pmc $O/rows_decode_pmc_summary.txt gemv_kernel "$grp" -- $R/tools/run_shapes.py 1,16384,16384
   pmc $O/rows_decode_pmc_summary.txt quantize_pack "$grp" -- $R/tools/time_pack.py 4096,4096
