@@ -232,11 +232,13 @@ static size_t rows_staged_lds_bytes(int mr, int ct, int64_t k) {
     const size_t image = (size_t)phase_steps * mr * 8 * 65 * 16, sums = (size_t)8 * mr * ct * 64 * 16;
     return image > sums ? image : sums;
 }
-// 16-channel tiles per workgroup: 1 while one round of workgroups covers n, else 2 or 4 (two-phase form: 1)
+// 16-channel tiles per workgroup: 1 while one round of workgroups covers n, else 2, 4 or 8 (two phases at 17 .. 32 rows: 1)
 static int rows_staged_tiles(int64_t m, int64_t n, int64_t k) {
     const int mr = m <= 16 ? 1 : 2;
     if (mr == 2 && k > 2048) return 1;
-    const int max_ct = mr == 1 ? (k > 4096 ? 2 : 4) : 2;   // (two phases with 4 tiles: 16 x 16384 x 8192 17.4 -> 17.8 us, not used)
+    // (measured beyond these: 16 x 16384 x 8192 with 4 tiles 17.4 -> 17.8 us, 16 x 28672 x 4096 with 8 tiles 14.5 -> 16.6: not used)
+    // (measured beyond these: 16 x 16384 x 8192 with 4 tiles 17.4 -> 17.8 us, 16 x 28672 x 4096 with 8 tiles 14.5 -> 16.6: not used)
+    const int max_ct = mr == 1 ? (k > 4096 ? 2 : (k > 2048 ? 4 : 8)) : 4;
     for (int ct = 1; ct < max_ct; ct *= 2) {
         int64_t per_cu = (int64_t)(160 * 1024) / (int64_t)(rows_staged_lds_bytes(mr, ct, k) + 1024);
         per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
@@ -394,14 +396,15 @@ static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x,
     do {                                             \
         if (ct == 1) TVL_STAGED(MR, 1, SPW, PH);     \
         if (ct == 2) TVL_STAGED(MR, 2, SPW, PH);     \
-        TVL_STAGED(MR, 4, SPW, PH);                  \
+        if (ct == 4 || MR == 2 || PH == 2) TVL_STAGED(MR, 4, SPW, PH); \
+        TVL_STAGED(MR, 8, SPW, PH);                  \
     } while (0)
     if (m <= 16) {
         if (k <= 2048) TVL_STAGED_CT(1, 1, 1);
         if (k <= 4096) TVL_STAGED_CT(1, 2, 1);
         TVL_STAGED_CT(1, 2, 2);
     }
-    if (k <= 2048) { if (ct == 1) TVL_STAGED(2, 1, 1, 1); TVL_STAGED(2, 2, 1, 1); }
+    if (k <= 2048) TVL_STAGED_CT(2, 1, 1);
     TVL_STAGED(2, 1, 1, 2);
 #undef TVL_STAGED_CT
 #undef TVL_STAGED
