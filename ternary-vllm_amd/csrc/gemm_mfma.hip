@@ -262,8 +262,10 @@ static int launch_mfma_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const 
 // sum_k w_k hi_k + sum_k w_k mid_k + sum_k w_k lo_k with exact products and float32 accumulation - a float32 dot
 // product in a different summation order.  The three planes are written side by side along k ([m][3k] bf16) into the
 // workspace, so the GEMM is the bf16 kernel over a k range of 3k whose weight rows wrap around every k.
+// Output layout: plane p of row r starts at xs + p * plane_off + r * ld_out (side by side along k: ld_out = 3k, plane_off = k; the
+// planes as three row blocks of an [3m][k] matrix: ld_out = k, plane_off = m k).
 __global__ void __launch_bounds__(256) split_f32_kernel(const float* __restrict__ x, int64_t m, int64_t k, int64_t ld_x,
-                                                        uint16_t* __restrict__ xs) {
+                                                        uint16_t* __restrict__ xs, int64_t ld_out, int64_t plane_off) {
     const int64_t per_row = k / 8, total = m * per_row;
     for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
         const int64_t row = u / per_row, c8 = u - row * per_row;
@@ -283,11 +285,21 @@ __global__ void __launch_bounds__(256) split_f32_kernel(const float* __restrict_
             mid[i] = (uint16_t)(mb >> 16);
             lo[i] = (uint16_t)(__float_as_uint(r2) >> 16);
         }
-        uint16_t* dst = xs + row * (3 * k) + 8 * c8;
+        uint16_t* dst = xs + row * ld_out + 8 * c8;
         *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(hi);
-        *reinterpret_cast<uint4*>(dst + k) = *reinterpret_cast<const uint4*>(mid);
-        *reinterpret_cast<uint4*>(dst + 2 * k) = *reinterpret_cast<const uint4*>(lo);
+        *reinterpret_cast<uint4*>(dst + plane_off) = *reinterpret_cast<const uint4*>(mid);
+        *reinterpret_cast<uint4*>(dst + 2 * plane_off) = *reinterpret_cast<const uint4*>(lo);
     }
+}
+
+// the three planes as row blocks of a bf16 [3m][k] matrix at xs (m * 3 * k * 2 bytes), for the few-row kernels: rows r, m + r, 2m + r
+// of the product are then added
+int launch_split_f32_rows(const float* x, int64_t m, int64_t k, int64_t ld_x, uint16_t* xs, hipStream_t st) {
+    int64_t g = ceil_div(m * (k / 8), 256);
+    g = g > 256 * 16 ? 256 * 16 : g;
+    hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)g), dim3(256), 0, st, x, m, k, ld_x, xs, k, m * k);
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
 }
 
 static inline size_t split_bytes(int64_t m, int64_t k) { return ((size_t)m * 3 * k * 2 + 255) & ~(size_t)255; }
@@ -325,7 +337,7 @@ int launch_gemm_mfma(const void* x, int x_dtype, int64_t m, int64_t k, int64_t l
         uint16_t* xs = (uint16_t*)workspace;
         int64_t g = ceil_div(m * (k / 8), 256);
         g = g > 256 * 16 ? 256 * 16 : g;
-        hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)x, m, k, ld_x, xs);
+        hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)x, m, k, ld_x, xs, 3 * k, k);
         TVL_LAUNCH_CHECK();
         const size_t used = split_bytes(m, k);
         return launch_mfma_x((const bf16_t*)xs, m, 3 * k, 3 * k, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y,

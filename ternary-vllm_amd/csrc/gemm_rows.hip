@@ -169,12 +169,22 @@ gemm_rows_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
 // activation traffic (m k n / 8 bytes) outgrows the weight stream: larger layers go to gemm_rows_shared_kernel below.  It is used
 // where it wins: 3 .. 16 rows (one or two rows go to the table-lookup kernel) up to m n k = 3e8, and 17 .. 32 rows on small layers.
 static bool rows_use_staged(int64_t m, int64_t n, int64_t k);
-bool gemm_rows_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw) {
+// float32 activations, 3 .. 10 rows: split into three bf16 planes stacked as 3m rows (workspace), one staged launch, the planes'
+// rows added in its reduction - where the staged kernel takes 3m rows (x in LDS, one round of workgroups)
+static bool rows_f32_planes_ok(int64_t m, int64_t n, int64_t k, const void* workspace, size_t workspace_bytes) {
+    if (m < 3 || m > 10 || k <= 0 || k % 256 != 0) return false;
+    if (workspace == nullptr || !aligned(workspace, 16) || workspace_bytes < (size_t)m * 3 * k * 2) return false;
+    return rows_use_staged(3 * m, n, k);
+}
+
+bool gemm_rows_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                         const void* workspace, size_t workspace_bytes) {
+    if (!aligned(pw, 16) || ld_pw % 16 != 0) return false;
+    if (n > INT32_MAX - 64 || k > INT32_MAX) return false;
+    if (x_dtype == TVL_F32) return aligned(x, 16) && (ld_x * 4) % 16 == 0 && rows_f32_planes_ok(m, n, k, workspace, workspace_bytes);
     if (x_dtype != TVL_F16 && x_dtype != TVL_BF16) return false;
     if (m < 3 || m > 32 || k <= 0 || k % 256 != 0) return false;
     if (!aligned(x, 16) || (ld_x * 2) % 16 != 0) return false;
-    if (!aligned(pw, 16) || ld_pw % 16 != 0) return false;
-    if (n > INT32_MAX - 64 || k > INT32_MAX) return false;
     const double work = (double)m * (double)n * (double)k;
     if (rows_use_staged(m, n, k)) return true;
     return m <= 16 ? work <= 3.0e8 : (double)n * (double)k <= 4.2e6;
@@ -210,17 +220,23 @@ static int launch_rows_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const 
 
 template <typename TX>
 static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
-                                const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
+                                const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, int planes, hipStream_t st);
 
 int launch_gemm_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                     const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
+                     const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y,
+                     void* workspace, size_t workspace_bytes, hipStream_t st) {
     if (y_dtype != TVL_F32 && y_dtype != TVL_F16 && y_dtype != TVL_BF16) {
         set_error("ternary_matmul: unsupported output dtype %d", y_dtype);
         return TVL_ERR_INVALID;
     }
+    if (x_dtype == TVL_F32) {
+        uint16_t* xs = reinterpret_cast<uint16_t*>(workspace);
+        if (int rc = launch_split_f32_rows((const float*)x, m, k, ld_x, xs, st); rc != TVL_OK) return rc;
+        return launch_rows_staged_x((const bf16_t*)xs, 3 * m, k, k, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, 3, st);
+    }
     if (rows_use_staged(m, n, k)) {
-        if (x_dtype == TVL_F16) return launch_rows_staged_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
-        return launch_rows_staged_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+        if (x_dtype == TVL_F16) return launch_rows_staged_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, 1, st);
+        return launch_rows_staged_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, 1, st);
     }
     if (x_dtype == TVL_F16) return launch_rows_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
     return launch_rows_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
@@ -260,7 +276,7 @@ template <typename TX, int MR, int CT, int SPW, int PH>   // CT: 16-channel tile
 __global__ void __launch_bounds__(512)
 gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
                         const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act, int act_begin, void* __restrict__ y,
-                        int y_dtype, int64_t ld_y) {
+                        int y_dtype, int64_t ld_y, int planes) {
     constexpr int WAVES = 8, FS = 65, IMG = 8 * FS, PS = WAVES * SPW;   // PS: steps per phase (k <= 256 * PS * PH)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4* xbuf = reinterpret_cast<uint4*>(lds_raw);                 // [steps of one phase][MR][8 fragments][FS]
@@ -365,6 +381,24 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
     __syncthreads();
     const float cl = fabsf(clip);
     const bool has_bias = bias != nullptr;
+    if (planes == 3) {
+        // float32 activations arrive as three bf16 planes in row blocks: rows r, m/3 + r, 2m/3 + r of the product are one output row
+        const int mo = m / 3;
+        for (int t = wave; t < CT; t += WAVES) {
+            floatx4 s = {0.f, 0.f, 0.f, 0.f};
+            if (c < mo) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const int R = pl * mo + c;
+                    const floatx4* src = red + ((R >> 4) * CT + t) * 64 + g * 16 + (R & 15);
+#pragma unroll
+                    for (int ww = 0; ww < WAVES; ++ww) s += src[ww * MR * CT * 64];
+                }
+            }
+            rows_store_fragment(s, c, n0 + 16 * t + 4 * g, mo, n, scale, bias, has_bias, act, cl, act_begin, y, y_dtype, ld_y);
+        }
+        return;
+    }
     for (int f = wave; f < MR * CT; f += WAVES) {
         const int i = f / CT, t = f % CT;
         floatx4 s = red[f * 64 + lane];
@@ -376,22 +410,22 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
 
 template <typename TX, int MR, int CT, int SPW, int PH>
 static int launch_rows_staged_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
-                                  const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
+                                  const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, int planes, hipStream_t st) {
     const size_t lds_bytes = rows_staged_lds_bytes(MR, CT, k);
     auto kern = gemm_rows_staged_kernel<TX, MR, CT, SPW, PH>;
     if (int rc = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc != TVL_OK) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(n, 16 * CT)), dim3(512), lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip,
-                       act, act_begin, y, y_dtype, ld_y);
+                       act, act_begin, y, y_dtype, ld_y, planes);
     TVL_LAUNCH_CHECK();
     return TVL_OK;
 }
 
 template <typename TX>
 static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
-                                const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st) {
+                                const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, int planes, hipStream_t st) {
     const int ct = rows_staged_tiles(m, n, k);
 #define TVL_STAGED(MR, CT, SPW, PH) \
-    return launch_rows_staged_cfg<TX, MR, CT, SPW, PH>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st)
+    return launch_rows_staged_cfg<TX, MR, CT, SPW, PH>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, planes, st)
 #define TVL_STAGED_CT(MR, SPW, PH)                   \
     do {                                             \
         if (ct == 1) TVL_STAGED(MR, 1, SPW, PH);     \

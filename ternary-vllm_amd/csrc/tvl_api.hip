@@ -158,8 +158,8 @@ static int dispatch_matmul(const void* x, int x_dtype, int64_t m, int64_t k, int
                            void* workspace, size_t workspace_bytes, hipStream_t st, bool allow_pad) {
     if (gemm_rows_shared_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
         return launch_gemm_rows_shared(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
-    if (gemm_rows_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
-        return launch_gemm_rows(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
+    if (gemm_rows_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))
+        return launch_gemm_rows(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, workspace, workspace_bytes, st);
     if (gemv_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw))
         return launch_gemv(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
     if (gemm_stream_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, workspace, workspace_bytes))

@@ -38,6 +38,7 @@ int launch_gemm_mfma(const void* x, int x_dtype, int64_t m, int64_t k, int64_t l
                      int64_t ld_pw, const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype,
                      int64_t ld_y, void* workspace, size_t workspace_bytes, hipStream_t st);
 size_t gemm_mfma_workspace_bytes(int x_dtype, int64_t m, int64_t n, int64_t k);
+int launch_split_f32_rows(const float* x, int64_t m, int64_t k, int64_t ld_x, uint16_t* xs, hipStream_t st);   // float32 -> three bf16 planes, [3m][k]
 int launch_splitk_reduce(const float* slab, int splits, int64_t m, int64_t n, const float* scale, const float* bias, float clip,
                          int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
 
@@ -51,9 +52,11 @@ int device_cu_count();                                            // compute uni
 int set_dynamic_lds_limit(const void* kernel, size_t lds_bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize), once per kernel and device
 
 // gemm_rows.hip: few activation rows (3 .. 32 on layers where it wins), one launch, no workspace
-bool gemm_rows_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw);
+bool gemm_rows_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                         const void* workspace, size_t workspace_bytes);
 int launch_gemm_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
-                     const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
+                     const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y,
+                     void* workspace, size_t workspace_bytes, hipStream_t st);
 
 // gemm_rows.hip, larger layers: 3 .. 64 rows, the activations shared through LDS by 8 waves, k split into float32 slabs at `workspace`
 bool gemm_rows_shared_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,

@@ -16,7 +16,7 @@ import ternary_vllm_amd as tv  # noqa: E402
 ops = tv.custom_ops_mod
 dev = torch.device("cuda:0")
 plan = os.environ.get("TVL_FORCE_PLAN", "auto")
-xdt = {"f16": torch.float16, "bf16": torch.bfloat16}[os.environ.get("XDT", "f16")]
+xdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[os.environ.get("XDT", "f16")]
 for spec in sys.argv[1:]:
     M, N, K = (int(a) for a in spec.split(","))
     nb = max(2, min(16, int(600e6 // max(1, N * K // 4 + M * K * 2))))
