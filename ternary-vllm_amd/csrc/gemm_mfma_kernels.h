@@ -381,6 +381,15 @@ gemm_mfma_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
 // weights per 16-channel tile); MFMA group s = 0, 1 takes the dword's halfword s and the activation chunk 2 q + s.
 // That assignment of q keeps the swizzled ds_read_b128 fragment reads conflict-free: the two lane groups that share
 // an LDS cycle read chunk indices whose bits 1 and 2 have equal parity.
+#ifdef TVL_CLOCK_PROBE
+// Diagnostic builds only (tools/hwtests/gemm_clock.hip): shader-clock and 100 MHz real-time stamps at kernel entry, around the k loop
+// and after the epilogue, 8 values per workgroup, into a buffer nothing else reads.
+__device__ unsigned long long tvl_clock_probe[8 * 4096];
+#define TVL_STAMP(i) do { stamp_c[i] = __builtin_amdgcn_s_memtime(); stamp_r[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TVL_STAMP(i) do { } while (0)
+#endif
+
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef uint32_t nts_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -408,15 +417,19 @@ __device__ __forceinline__ floatx4 mfma16(uint4 a, uint4 b, floatx4 c) {
 // nothing).  (Tried and dropped: two 4-wave groups per workgroup taking alternate k steps of one tile with an exchange of
 // half the accumulators through LDS at the end - no faster than one group with NB = 4.)
 template <typename TX, typename TY, bool HAS_BIAS, int ACT, int WAVES_M, bool PERSIST, int NB, int BM_ = 256, int WAVES = 8, bool SPLIT = false,
-          int MIN_WAVES = 2>
+          int MIN_WAVES = 2, int WN_ = 32>
 __global__ void __launch_bounds__(64 * WAVES, MIN_WAVES)
 gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
                    const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act_begin, TY* __restrict__ y,
                    int64_t ld_y, int tiles_n, int nblk, int w_steps, int steps_per_split) {
     static_assert(!(SPLIT && PERSIST), "a split k range belongs to one tile");
     static_assert(BM_ % 32 == 0 && (BM_ * 8) % (64 * WAVES) == 0, "tile / workgroup mismatch");
+#ifdef TVL_CLOCK_PROBE
+    unsigned long long stamp_c[4], stamp_r[4];
+    TVL_STAMP(0);
+#endif
     constexpr int WAVES_N = WAVES / WAVES_M;
-    constexpr int BM = BM_, BN = (WAVES_M == 1 ? 32 : 64) * WAVES_N, NT = 64 * WAVES;
+    constexpr int BM = BM_, BN = (WAVES_M == 1 ? WN_ : 64) * WAVES_N, NT = 64 * WAVES;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile: BM x 32 (or BM / 2 x 64)
     constexpr int MT = WM / 16, NTL = WN / 16;            // 16 x 16 tiles per wave: 16 x 2 or 8 x 4
     constexpr int MH = MT / 2, NH = NTL / 2;              // per phase: MH row tiles x NTL channel tiles, NH decodes
@@ -698,6 +711,7 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     read_a(0, 0, 0, afA);
     decode_part(bq0, 0, 0, bf0);
     decode_part(bq0, 0, 1, bf0);
+    TVL_STAMP(1);
     // unrolled by NB: LDS buffers and weight registers have static roles.  Step J multiplies with set J, decodes ahead from set
     // J + 1 and issues the loads that fill set J - 1 (all modulo NB).
 #define TVL_STEP(J, W0, W1, WN) step(std::integral_constant<int, (J)>{}, W0, W1, WN)
@@ -739,7 +753,16 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     wait_loads(bq3);
     wait_loads(bq4);
     wait_loads(bq5);
+    TVL_STAMP(2);
     if constexpr (!PERSIST) store_tile();
+#ifdef TVL_CLOCK_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave's queue
+    TVL_STAMP(3);
+    if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { tvl_clock_probe[8 * blockIdx.x + i] = stamp_c[i]; tvl_clock_probe[8 * blockIdx.x + 4 + i] = stamp_r[i]; }
+    }
+#endif
 }
 
 }  // namespace tvl

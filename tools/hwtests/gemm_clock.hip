@@ -1,0 +1,82 @@
+// In-kernel clock of the 256 x 256 packed-ternary GEMM tile under sustained load: builds the product's own kernel template with
+// shader-clock (s_memtime) and 100 MHz (s_memrealtime) stamps at entry, around the k loop and after the epilogue, runs back-to-back
+// launches on random data for ~2 s and prints, as medians over workgroups of the LAST launch: the clock held over the k loop,
+// cycles and microseconds of prologue / loop / epilogue, cycles per 64-deep k step.
+//   usage: gemm_clock [wide=0|1] [M N K]
+#define TVL_CLOCK_PROBE 1
+#include "../../ternary-vllm_amd/csrc/gemm_mfma_kernels.h"
+
+#include <algorithm>
+#include <stdlib.h>
+#include <vector>
+
+namespace tvl { void set_error(const char*, ...) {} }
+using namespace tvl;
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
+
+template <int WAVES, int WN, int MINW>
+static void run(int m, int n, int k, const f16* x, const uint8_t* pw, const float* sc, const float* bi, f16* y) {
+    constexpr int NB = 4;
+    auto kern = gemm_mfma16_kernel<f16, f16, true, TVL_ACT_NONE, 1, false, NB, 256, WAVES, false, MINW, WN>;
+    const size_t lds = (size_t)NB * 256 * ROW_BYTES;
+    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int tiles_n = (n + 255) / 256, nblk = ((m + 255) / 256) * tiles_n;
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    float ms = 0;
+    int launches = 0;
+    for (int round = 0; round < 8; ++round) {   // ~8 x 2500 x 0.1 ms = 2 s
+        CHECK(hipEventRecord(a, 0));
+        for (int i = 0; i < 2500; ++i)
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WAVES), lds, 0, x, m, k, (int64_t)k, pw, n, (int64_t)(k / 4), sc, bi, 100.0f, 0, y, (int64_t)n,
+                               tiles_n, nblk, k / 64, 0);
+        CHECK(hipEventRecord(b, 0)); CHECK(hipEventSynchronize(b));
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        launches += 2500;
+    }
+    std::vector<unsigned long long> h(8 * 4096);
+    CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(tvl_clock_probe), h.size() * 8));
+    std::vector<double> ghz, pro, loop, epi, pro_us, loop_us, epi_us, all_us;
+    unsigned long long r_first = ~0ull, r_last = 0;
+    for (int bl = 0; bl < std::min(nblk, 4096); ++bl) {
+        const unsigned long long* c = &h[8 * bl]; const unsigned long long* r = c + 4;
+        ghz.push_back((double)(c[2] - c[1]) / (double)(r[2] - r[1]) * 0.1);
+        pro.push_back((double)(c[1] - c[0])); loop.push_back((double)(c[2] - c[1])); epi.push_back((double)(c[3] - c[2]));
+        pro_us.push_back((r[1] - r[0]) * 0.01); loop_us.push_back((r[2] - r[1]) * 0.01); epi_us.push_back((r[3] - r[2]) * 0.01);
+        all_us.push_back((r[3] - r[0]) * 0.01);
+        r_first = std::min(r_first, r[0]); r_last = std::max(r_last, r[3]);
+    }
+    printf("waves %d x %d channels: %.2f us per launch (event pair, last round of %d launches)\n", WAVES, WN, ms / 2500 * 1e3, launches);
+    printf("  clock over the k loop %.3f GHz (median of %d workgroups)\n", med(ghz), (int)ghz.size());
+    printf("  prologue %.0f cyc / %.2f us   k loop %.0f cyc / %.2f us (%.0f cyc per step; matrix pipe %.0f = %.1f %%)   epilogue %.0f cyc / %.2f us   workgroup lifetime %.2f us\n",
+           med(pro), med(pro_us), med(loop), med(loop_us), med(loop) / (k / 64), 2048.0, 100.0 * 2048.0 * (k / 64) / med(loop), med(epi), med(epi_us), med(all_us));
+    printf("  first workgroup entry to last workgroup exit: %.2f us\n", (r_last - r_first) * 0.01);
+}
+
+int main(int argc, char** argv) {
+    const int wide = argc > 1 ? atoi(argv[1]) : 0;
+    const int m = argc > 4 ? atoi(argv[2]) : 4096, n = argc > 4 ? atoi(argv[3]) : 4096, k = argc > 4 ? atoi(argv[4]) : 4096;
+    std::vector<uint16_t> hx((size_t)m * k);
+    std::vector<uint8_t> hw((size_t)n * k / 4);
+    std::vector<float> hs(n), hb(n);
+    uint64_t s = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (auto& v : hx) {   // roughly normal f16: sum of four uniforms, centred
+        const uint64_t r = rnd();
+        const float f = ((r & 0xFFFF) + ((r >> 16) & 0xFFFF) + ((r >> 32) & 0xFFFF) + ((r >> 48) & 0xFFFF)) / 65536.0f - 2.0f;
+        const _Float16 hf = (_Float16)(f * 1.7f);
+        v = *reinterpret_cast<const uint16_t*>(&hf);
+    }
+    for (auto& v : hw) { const uint64_t r = rnd(); v = (uint8_t)((r % 3) | (((r >> 8) % 3) << 2) | (((r >> 16) % 3) << 4) | (((r >> 24) % 3) << 6)); }
+    for (int i = 0; i < n; ++i) { hs[i] = 0.5f + (rnd() & 0xFFFF) / 65536.0f; hb[i] = (float)(rnd() & 0xFF) / 64.0f - 2.0f; }
+    f16 *x, *y; uint8_t* pw; float *sc, *bi;
+    CHECK(hipMalloc(&x, hx.size() * 2)); CHECK(hipMalloc(&y, (size_t)m * n * 2)); CHECK(hipMalloc(&pw, hw.size()));
+    CHECK(hipMalloc(&sc, n * 4)); CHECK(hipMalloc(&bi, n * 4));
+    CHECK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CHECK(hipMemcpy(pw, hw.data(), hw.size(), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(sc, hs.data(), n * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(bi, hb.data(), n * 4, hipMemcpyHostToDevice));
+    if (wide) run<4, 64, 1>(m, n, k, x, pw, sc, bi, y);
+    else run<8, 32, 2>(m, n, k, x, pw, sc, bi, y);
+    return 0;
+}
