@@ -164,7 +164,7 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
 // kind: KIND_BIG = the 256 x 256 tile, KIND_MID = 128-row tiles of the same 16x16x32 kernel (gemm_mid.hip), KIND_SMALL = the
 // 32x32x16 kernel's 64- and 32-row tiles (few rows per tile: a decoded weight feeds only one or two row tiles there)
 enum { KIND_SMALL = 0, KIND_MID = 1, KIND_BIG = 2 };
-struct GemmPlan { int kind, bm, bn, splits; };
+struct GemmPlan { int kind, bm, bn, splits; double us; };   // us: modelled time (0 for a forced plan)
 // step_light: time per k step of a workgroup alone on its CU while at most ~60 % of the CUs are busy; step_full: the same
 // with every CU busy (the shared L2 / fabric path slows the tile loads down); step_shared: per workgroup-step when two or more
 // share a CU.  Measured with TVL_FORCE_PLAN over M = 256 .. 4096 at N = K = 4096 and the moondream prefill shapes.
@@ -180,7 +180,7 @@ static const TileCost TILE_COSTS[] = {
 // TVL_FORCE_PLAN="kind:bm:bn:splits" pins the choice (tuning and tests: every tile can be timed on every shape); read once.
 static bool forced_plan(GemmPlan* p) {
     static const GemmPlan forced = [] {
-        GemmPlan f{-1, 0, 0, 0};
+        GemmPlan f{-1, 0, 0, 0, 0.0};
         if (const char* e = getenv("TVL_FORCE_PLAN")) {
             if (sscanf(e, "%d:%d:%d:%d", &f.kind, &f.bm, &f.bn, &f.splits) != 4) f.kind = -1;
         }
@@ -194,8 +194,9 @@ static bool forced_plan(GemmPlan* p) {
 static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_bytes) {
     const int64_t steps = k / BK;
     const int64_t max_by_ws = (int64_t)(workspace_bytes / ((size_t)m * n * sizeof(float)));
-    GemmPlan best{KIND_MID, 128, 128, 1};
+    GemmPlan best{KIND_MID, 128, 128, 1, 0.0};
     if (forced_plan(&best)) {
+        if (best.splits < 0) return best;   // the two-workgroups-per-CU form of the 128 x 256 tile
         if (best.splits > max_by_ws) best.splits = max_by_ws > 1 ? (int)max_by_ws : 1;
         if (best.splits > steps) best.splits = (int)steps;
         return best;
@@ -218,12 +219,32 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_byte
             // so does the 128 x 256 tile (gemm_mid.hip), at ~6 us per tile for its epilogue under the next tile's first steps
             if (tc.kind == KIND_MID && tc.bn == 256 && s == 1 && tiles > cus) t = tc.fixed_us + load * ((double)per * 0.9 + 6.0);
             if (s > 1) t += 3.0 + 3.0 * (double)s * (double)m * (double)n * 4.0 / 8.0e6;
-            if (t < best_t) { best_t = t; best = GemmPlan{tc.kind, tc.bm, tc.bn, (int)s}; }
+            if (t < best_t) { best_t = t; best = GemmPlan{tc.kind, tc.bm, tc.bn, (int)s, t}; }
         }
     }
     return best;
 }
 
+// A persistent grid of 256 x 256 tiles whose last round is mostly empty (tiles = 3.48 x the compute units runs as long as 4.0 x):
+// the rows that fill whole rounds go to the big tile, the remaining rows are a product of their own on smaller tiles (a second
+// launch; rows are independent, so the results are the same bits).  Returns the rows of the first part, 0 = no split.
+// TVL_TAIL_SPLIT=0 turns it off (tuning).
+static int64_t tail_split_rows(const GemmPlan& p, int64_t m, int64_t n, int64_t k, size_t workspace_bytes) {
+    static const bool enabled = [] { const char* e = getenv("TVL_TAIL_SPLIT"); return !e || atoi(e) != 0; }();
+    if (!enabled || p.us <= 0.0) return 0;
+    const int cus = device_cu_count();
+    const int64_t tiles_n = ceil_div(n, 256), tiles = ceil_div(m, 256) * tiles_n;
+    const int64_t rounds = tiles / cus;
+    if (rounds < 1 || tiles % cus == 0) return 0;
+    const int64_t m1 = (rounds * cus / tiles_n) * 256;   // rows of whole 256-row tiles that fit into `rounds` rounds
+    if (m1 <= 0 || m1 >= m) return 0;
+    // the big tile on the first part (the cost table's first row): one k loop per round, ~4 us of epilogue per further tile
+    const TileCost& big = TILE_COSTS[0];
+    const double per = (double)(k / BK);
+    const double t1 = rounds == 1 ? big.fixed_us + per * big.step_full_us : big.fixed_us + (double)rounds * (per * big.step_full_us + 4.0);
+    const GemmPlan p2 = plan_gemm(m - m1, n, k, workspace_bytes);
+    return t1 + p2.us + 2.0 < p.us ? m1 : 0;
+}
 
 template <typename TX, typename TY>
 static int launch_mfma_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
@@ -232,6 +253,20 @@ static int launch_mfma_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const
     const bool ws_ok = workspace != nullptr && aligned(workspace, 16);
     const GemmPlan p = plan_gemm(m, n, k, ws_ok ? workspace_bytes : 0);
     float* slab = (float*)workspace;
+    if (const int64_t m1 = tail_split_rows(p, m, n, k, ws_ok ? workspace_bytes : 0)) {
+        int rc = launch_cfg<TX, TY, 256, 256, 1, 8>(x, m1, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, 1, slab, w_steps, st);
+        if (rc != TVL_OK) return rc;
+        const GemmPlan p2 = plan_gemm(m - m1, n, k, ws_ok ? workspace_bytes : 0);
+        const TX* x2 = x + m1 * ld_x;
+        TY* y2 = y + m1 * ld_y;
+        if (p2.kind == KIND_BIG)
+            return launch_cfg<TX, TY, 256, 256, 1, 8>(x2, m - m1, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y2, ld_y, 1, slab, w_steps, st);
+        if (p2.kind == KIND_MID)
+            return launch_gemm_mid(x2, std::is_same<TX, f16>::value ? TVL_F16 : TVL_BF16, m - m1, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin,
+                                   y2, std::is_same<TY, float>::value ? TVL_F32 : (std::is_same<TY, f16>::value ? TVL_F16 : TVL_BF16), ld_y, p2.bm, p2.bn,
+                                   p2.splits, slab, w_steps, st);
+        return launch_cfg<TX, TY, 32, 128, 1, 4>(x2, m - m1, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y2, ld_y, p2.splits, slab, w_steps, st);
+    }
     if (p.kind == KIND_BIG)
         return launch_cfg<TX, TY, 256, 256, 1, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, 1, slab, w_steps, st);
     if (p.kind == KIND_MID)
@@ -304,13 +339,19 @@ int launch_split_f32_rows(const float* x, int64_t m, int64_t k, int64_t ld_x, ui
 
 static inline size_t split_bytes(int64_t m, int64_t k) { return ((size_t)m * 3 * k * 2 + 255) & ~(size_t)255; }
 
-size_t gemm_mfma_workspace_bytes(int x_dtype, int64_t m, int64_t n, int64_t k) {
-    if (x_dtype == TVL_F32) {
-        const GemmPlan p = plan_gemm(m, n, 3 * k, (size_t)1 << 40);
-        return split_bytes(m, k) + (p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0);
-    }
+// float32 slabs of the k split the plan for m x n x k would use with unlimited workspace
+static size_t slab_bytes(int64_t m, int64_t n, int64_t k) {
     const GemmPlan p = plan_gemm(m, n, k, (size_t)1 << 40);
+    if (const int64_t m1 = tail_split_rows(p, m, n, k, (size_t)1 << 40)) {   // the remainder's k split, if it has one
+        const GemmPlan p2 = plan_gemm(m - m1, n, k, (size_t)1 << 40);
+        return p2.splits > 1 ? (size_t)p2.splits * (m - m1) * n * sizeof(float) : 0;
+    }
     return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
+}
+
+size_t gemm_mfma_workspace_bytes(int x_dtype, int64_t m, int64_t n, int64_t k) {
+    if (x_dtype == TVL_F32) return split_bytes(m, k) + slab_bytes(m, n, 3 * k);
+    return slab_bytes(m, n, k);
 }
 
 bool gemm_mfma_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,

@@ -417,7 +417,7 @@ __device__ __forceinline__ floatx4 mfma16(uint4 a, uint4 b, floatx4 c) {
 // nothing).  (Tried and dropped: two 4-wave groups per workgroup taking alternate k steps of one tile with an exchange of
 // half the accumulators through LDS at the end - no faster than one group with NB = 4.)
 template <typename TX, typename TY, bool HAS_BIAS, int ACT, int WAVES_M, bool PERSIST, int NB, int BM_ = 256, int WAVES = 8, bool SPLIT = false,
-          int MIN_WAVES = 2, int WN_ = 32>
+          int MIN_WAVES = 2, int WN_ = 32, int PARTS = 2>
 __global__ void __launch_bounds__(64 * WAVES, MIN_WAVES)
 gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
                    const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act_begin, TY* __restrict__ y,
@@ -433,6 +433,8 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile: BM x 32 (or BM / 2 x 64)
     constexpr int MT = WM / 16, NTL = WN / 16;            // 16 x 16 tiles per wave: 16 x 2 or 8 x 4
     constexpr int MH = MT / 2, NH = NTL / 2;              // per phase: MH row tiles x NTL channel tiles, NH decodes
+    constexpr int MP = MT / PARTS;                        // PARTS != 2: phases of MP row tiles (fewer fragment registers: more waves per SIMD)
+    static_assert(MT % PARTS == 0 && (PARTS == 2 || (PARTS % NTL == 0 && !PERSIST)), "phase split");
     constexpr int A_TILE_BYTES = BM * ROW_BYTES;
     constexpr int ROUNDS = (BM * 8) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NB * A_TILE_BYTES
@@ -553,6 +555,18 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
 #pragma unroll
             for (int t = 0; t < NTL; ++t) acc[MH * half + i][t] = mfma16<TX>(bf[t], af[i], acc[MH * half + i][t]);
     };
+    // the same in PARTS row parts per MFMA group (PARTS != 2)
+    auto read_a_g = [&](int buf, int s, int part, uint4 (&af)[MP]) __attribute__((always_inline)) {
+        const unsigned char* abase = lds + buf * A_TILE_BYTES + a_row_off + a_col_off[s] + part * MP * 16 * ROW_BYTES;
+#pragma unroll
+        for (int i = 0; i < MP; ++i) af[i] = *reinterpret_cast<const uint4*>(abase + i * 16 * ROW_BYTES);
+    };
+    auto mma_g = [&](const uint4 (&af)[MP], int part, const uint4 (&bf)[NTL]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MP; ++i)
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) acc[MP * part + i][t] = mfma16<TX>(bf[t], af[i], acc[MP * part + i][t]);
+    };
     // decode NH of the NTL weight fragments of MFMA group s (the half `part`) from the packed dwords w
     auto decode_part = [&](const uint32_t (&w)[NTL], int s, int part, uint4 (&bf)[NTL]) {
 #pragma unroll
@@ -640,12 +654,54 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     // (caught by the build's assembly audit).
     uint32_t bq0[NTL], bq1[NTL], bq2[NTL], bq3[NTL], bq4[NTL], bq5[NTL];
     uint4 afA[MH], afB[MH], bf0[NTL], bf1[NTL];   // bf0 / bf1: decoded weights of MFMA group s = 0 / 1
+    uint4 afG0[MP], afG1[MP];                     // PARTS != 2: fragments of even / odd phases
+    // PARTS != 2: one phase p of the 2 PARTS phases of a step (MFMA group s = p / PARTS, row part p % PARTS): request the next
+    // phase's activation fragments, decode one weight fragment of the next MFMA group every PARTS / NTL phases, multiply
+    auto phase_g = [&](auto p_c, auto buf_c, uint32_t (&w0)[NTL], uint32_t (&w1)[NTL], uint32_t (&wn)[NTL]) __attribute__((always_inline)) {
+        constexpr int p = decltype(p_c)::value, buf = decltype(buf_c)::value;
+        constexpr int s = p / PARTS, part = p % PARTS;
+        constexpr int pn = p + 1, sn = (pn / PARTS) & 1, partn = pn % PARTS;
+        constexpr int bufr = pn == 2 * PARTS ? (buf + 1) % NB : buf;
+        constexpr int every = PARTS / NTL;                 // a fragment is decoded in phases part = every * t
+        if constexpr ((pn & 1) == 0) read_a_g(bufr, sn, partn, afG0); else read_a_g(bufr, sn, partn, afG1);
+        if constexpr (p == PARTS) issue_loads((buf + NB - 1) % NB, wn);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (part % every == 0) {
+            if constexpr (s == 0) bf1[part / every] = decode_b(w0[part / every], 1);
+            else bf0[part / every] = decode_b(w1[part / every], 0);
+        }
+        if constexpr ((p & 1) == 0) { if constexpr (s == 0) mma_g(afG0, part, bf0); else mma_g(afG0, part, bf1); }
+        else { if constexpr (s == 0) mma_g(afG1, part, bf0); else mma_g(afG1, part, bf1); }
+#pragma unroll
+        for (int j = 0; j < MP * NTL; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, part % every == 0 ? (16 + MP * NTL - 1) / (MP * NTL) : 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (p == PARTS - 1) {   // middle of the step: tile kb+1 (and its weights w1) complete, tile kb-1 retired
+            if constexpr (NB == 3) wait_loads(w1);
+            else wait_loads_keep_newest(w1);
+            __builtin_amdgcn_s_barrier();
+        }
+    };
     // one step = four phases (s, half of the 16 row tiles); each phase reads the NEXT phase's activation fragments
     // first, then interleaves its 16 MFMAs with the decode of one weight fragment needed two phases later
     // w0 / w1: weights of this step and the next; wn: the registers the loads issued in this step (for step + NB - 1) fill
     auto step = [&](auto buf_c, uint32_t (&w0)[NTL], uint32_t (&w1)[NTL], uint32_t (&wn)[NTL]) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_c)::value;
         constexpr int buf1 = (buf + 1) % NB, bufn = (buf + NB - 1) % NB;
+        if constexpr (PARTS != 2) {
+            static_assert(PARTS == 2 || PARTS == 4, "two or four row parts per MFMA group");
+            phase_g(std::integral_constant<int, 0>{}, buf_c, w0, w1, wn);
+            phase_g(std::integral_constant<int, 1>{}, buf_c, w0, w1, wn);
+            phase_g(std::integral_constant<int, 2>{}, buf_c, w0, w1, wn);
+            phase_g(std::integral_constant<int, 3>{}, buf_c, w0, w1, wn);
+            phase_g(std::integral_constant<int, 4>{}, buf_c, w0, w1, wn);
+            phase_g(std::integral_constant<int, 5>{}, buf_c, w0, w1, wn);
+            phase_g(std::integral_constant<int, 6>{}, buf_c, w0, w1, wn);
+            phase_g(std::integral_constant<int, 7>{}, buf_c, w0, w1, wn);
+            return;
+        }
         read_a(buf, 0, 1, afB);
         __builtin_amdgcn_sched_barrier(0);
         decode_part(w0, 1, 0, bf1); mma(afA, 0, bf0);
@@ -708,7 +764,8 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         bq5[t] = 0;
     }
     __builtin_amdgcn_s_barrier();
-    read_a(0, 0, 0, afA);
+    if constexpr (PARTS == 2) read_a(0, 0, 0, afA);
+    else read_a_g(0, 0, 0, afG0);
     decode_part(bq0, 0, 0, bf0);
     decode_part(bq0, 0, 1, bf0);
     TVL_STAMP(1);

@@ -13,6 +13,33 @@ namespace tvl {
 
 constexpr int MID_NB = 4;   // activation tiles in LDS: a tile is requested two steps before its use
 
+// The 128 x 256 tile in its low-register form (four row parts per MFMA group: <= 128 registers), so that TWO workgroups share a
+// compute unit (4 waves per SIMD, 2 x 64 KiB of LDS): their prologues, k loops and epilogues overlap each other.
+template <typename TX, typename TY>
+static int launch_mid_dual(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
+                           const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, int w_steps, hipStream_t st) {
+    constexpr int BM = 128, BN = 256;
+    const int tiles_m = (int)ceil_div(m, BM), tiles_n = (int)ceil_div(n, BN);
+    const int nblk = tiles_m * tiles_n;
+    const size_t lds_bytes = (size_t)MID_NB * BM * ROW_BYTES;
+    int rc;
+#define TVL_DUAL(HB, ACT)                                                                                                   \
+    do {                                                                                                                    \
+        auto kern = gemm_mfma16_kernel<TX, TY, HB, ACT, 1, false, MID_NB, BM, 8, false, 4, 32, 4>;                          \
+        if ((rc = set_dynamic_lds_limit((const void*)kern, lds_bytes)) != TVL_OK) return rc;                                \
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, \
+                           act_begin, y, ld_y, tiles_n, nblk, w_steps, 0);                                                  \
+    } while (0)
+    if (bias) {
+        if (act == TVL_ACT_GELU_TANH) TVL_DUAL(true, TVL_ACT_GELU_TANH); else TVL_DUAL(true, TVL_ACT_NONE);
+    } else {
+        if (act == TVL_ACT_GELU_TANH) TVL_DUAL(false, TVL_ACT_GELU_TANH); else TVL_DUAL(false, TVL_ACT_NONE);
+    }
+#undef TVL_DUAL
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
 template <typename TX, typename TY, int BM, int WAVES>
 static int launch_mid_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                           const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, int splits, float* slab, int w_steps,
@@ -70,6 +97,8 @@ template <typename TX, typename TY>
 static int launch_mid_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                          const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, int bm, int bn, int splits, float* slab,
                          int w_steps, hipStream_t st) {
+    if (bm == 128 && bn == 256 && splits < 0)   // (splits = -1: the two-workgroups-per-CU form)
+        return launch_mid_dual<TX, TY>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, w_steps, st);
     if (bm == 128 && bn == 256)
         return launch_mid_cfg<TX, TY, 128, 8>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, splits, slab, w_steps, st);
     if (bm == 128 && bn == 128)

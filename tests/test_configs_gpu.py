@@ -100,6 +100,20 @@ def test_headline_4096_full_output_and_randn_rows(ops, dev, c_oracle):
     assert rel_gpu <= max(2.0 * rel_cpu, 2.0 ** -22)
 
 
+def test_rows_beyond_whole_rounds_of_big_tiles_go_to_a_second_launch(ops, dev, c_oracle):
+    """4500 x 4096 x 4096: 288 tiles of 256 x 256 on 256 compute units.  The library gives the 4096 rows that fill one round to
+    the big tile and the other 404 rows to smaller tiles in a second launch; every output against the C restatement."""
+    m, n, k = 4500, 4096, 4096
+    x, w, scale, bias = _problem(4500, m, n, k)
+    want_pw = O.pack_format_c(O.ternarize(w))
+    pw = torch.from_numpy(want_pw).to(dev)
+    want = c_oracle(x, want_pw, scale, bias, 100.0)
+    st, bt = torch.from_numpy(scale).to(dev), torch.from_numpy(bias).to(dev)
+    for xdt in (torch.float16, torch.bfloat16):
+        got = ops.ternary_matmul(torch.from_numpy(x).to(dev).to(xdt), pw, st, bt, 100.0, out_dtype=torch.float32)
+        assert np.array_equal(got.cpu().numpy(), want), xdt
+
+
 @pytest.mark.parametrize("method", ["select", "matmul"])
 def test_config1_ternary_mm_at_the_files_own_size(ops, dev, method):
     """matrix_mul_tests.py:8-9,16-18: 1024 x 1024 operands, half of the weights zeroed.  Grid activations, so the select-and-sum
@@ -114,13 +128,14 @@ def test_config1_ternary_mm_at_the_files_own_size(ops, dev, method):
     assert np.array_equal(want, m_ @ np.sign(tm).T)
 
 
-PLANS = ["2:256:256:1", "1:128:256:1", "1:128:256:3", "1:128:128:1", "1:128:128:4", "1:64:128:1", "1:64:128:5", "0:64:128:3", "0:32:128:2", "0:128:128:2"]
+PLANS = ["2:256:256:1", "1:128:256:1", "1:128:256:-1", "1:128:256:3", "1:128:128:1", "1:128:128:4", "1:64:128:1", "1:64:128:5", "0:64:128:3", "0:32:128:2", "0:128:128:2"]
 
 
 @pytest.mark.parametrize("plan", PLANS)
 def test_every_tile_plan_is_exact_when_pinned(plan):
     """The planner picks a tile and a split-K factor per shape, so a test shape exercises one of them.  Here every tile of the
-    matrix-core kernels (256 x 256, 128 x 256, 128 x 128, the 64- and 32-row tiles) is pinned in turn, with and without split-K,
+    matrix-core kernels (256 x 256, 128 x 256 - also in its two-workgroups-per-CU form, splits = -1 -, 128 x 128, the 64- and
+    32-row tiles) is pinned in turn, with and without split-K,
     on ragged shapes (edge tiles, odd step counts, float32 activations as three wrapped bf16 planes, the activation from a
     channel on, code 3) in a child process - the library reads TVL_FORCE_PLAN once - and compared with the CPU oracle."""
     import os
