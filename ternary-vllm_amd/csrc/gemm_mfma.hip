@@ -225,25 +225,31 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_byte
     return best;
 }
 
-// A persistent grid of 256 x 256 tiles whose last round is mostly empty (tiles = 3.48 x the compute units runs as long as 4.0 x):
-// the rows that fill whole rounds go to the big tile, the remaining rows are a product of their own on smaller tiles (a second
-// launch; rows are independent, so the results are the same bits).  Returns the rows of the first part, 0 = no split.
-// TVL_TAIL_SPLIT=0 turns it off (tuning).
-static int64_t tail_split_rows(const GemmPlan& p, int64_t m, int64_t n, int64_t k, size_t workspace_bytes) {
+// A persistent grid whose last round is mostly empty (tiles = 3.48 x the compute units runs as long as 4.0 x): the rows that fill
+// whole rounds of 256 x 256 (or 128 x 256) tiles go to that tile, the remaining rows are a product of their own on smaller tiles
+// (a second launch; rows are independent, so the results are the same bits).  Returns the rows of the first part and its tile
+// height in *head_bm; 0 = no split.  TVL_TAIL_SPLIT=0 turns it off (tuning).
+static int64_t tail_split_rows(const GemmPlan& p, int64_t m, int64_t n, int64_t k, size_t workspace_bytes, int* head_bm) {
     static const bool enabled = [] { const char* e = getenv("TVL_TAIL_SPLIT"); return !e || atoi(e) != 0; }();
     if (!enabled || p.us <= 0.0) return 0;
     const int cus = device_cu_count();
-    const int64_t tiles_n = ceil_div(n, 256), tiles = ceil_div(m, 256) * tiles_n;
-    const int64_t rounds = tiles / cus;
-    if (rounds < 1 || tiles % cus == 0) return 0;
-    const int64_t m1 = (rounds * cus / tiles_n) * 256;   // rows of whole 256-row tiles that fit into `rounds` rounds
-    if (m1 <= 0 || m1 >= m) return 0;
-    // the big tile on the first part (the cost table's first row): one k loop per round, ~4 us of epilogue per further tile
-    const TileCost& big = TILE_COSTS[0];
     const double per = (double)(k / BK);
-    const double t1 = rounds == 1 ? big.fixed_us + per * big.step_full_us : big.fixed_us + (double)rounds * (per * big.step_full_us + 4.0);
-    const GemmPlan p2 = plan_gemm(m - m1, n, k, workspace_bytes);
-    return t1 + p2.us + 2.0 < p.us ? m1 : 0;
+    const int64_t tiles_n = ceil_div(n, 256);
+    int64_t best_m1 = 0;
+    double best_t = 0.97 * p.us;   // a second launch has to buy at least 3 %
+    for (const int bm : {256, 128}) {
+        const int64_t tiles = ceil_div(m, bm) * tiles_n, rounds = tiles / cus;
+        if (rounds < 1 || tiles % cus == 0) continue;
+        const int64_t m1 = (rounds * cus / tiles_n) * bm;   // rows of whole tiles that fit into `rounds` rounds
+        if (m1 <= 0 || m1 >= m) continue;
+        // the cost table's rows of these two tiles: one k loop per round, the epilogue under the next tile's first steps
+        const TileCost& tc = TILE_COSTS[bm == 256 ? 0 : 1];
+        const double t1 = bm == 256 ? (rounds == 1 ? tc.fixed_us + per * tc.step_full_us : tc.fixed_us + (double)rounds * (per * tc.step_full_us + 4.0))
+                                    : (rounds == 1 ? tc.fixed_us + per * tc.step_full_us : tc.fixed_us + (double)rounds * (per * 0.9 + 6.0));
+        const double t = t1 + plan_gemm(m - m1, n, k, workspace_bytes).us + 2.0;
+        if (t < best_t) { best_t = t; best_m1 = m1; *head_bm = bm; }
+    }
+    return best_m1;
 }
 
 template <typename TX, typename TY>
@@ -253,8 +259,12 @@ static int launch_mfma_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const
     const bool ws_ok = workspace != nullptr && aligned(workspace, 16);
     const GemmPlan p = plan_gemm(m, n, k, ws_ok ? workspace_bytes : 0);
     float* slab = (float*)workspace;
-    if (const int64_t m1 = tail_split_rows(p, m, n, k, ws_ok ? workspace_bytes : 0)) {
-        int rc = launch_cfg<TX, TY, 256, 256, 1, 8>(x, m1, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, 1, slab, w_steps, st);
+    constexpr int XD = std::is_same<TX, f16>::value ? TVL_F16 : TVL_BF16;
+    constexpr int YD = std::is_same<TY, float>::value ? TVL_F32 : (std::is_same<TY, f16>::value ? TVL_F16 : TVL_BF16);
+    int head_bm = 0;
+    if (const int64_t m1 = tail_split_rows(p, m, n, k, ws_ok ? workspace_bytes : 0, &head_bm)) {
+        int rc = head_bm == 256 ? launch_cfg<TX, TY, 256, 256, 1, 8>(x, m1, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, 1, slab, w_steps, st)
+                                : launch_gemm_mid(x, XD, m1, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, YD, ld_y, 128, 256, 1, slab, w_steps, st);
         if (rc != TVL_OK) return rc;
         const GemmPlan p2 = plan_gemm(m - m1, n, k, ws_ok ? workspace_bytes : 0);
         const TX* x2 = x + m1 * ld_x;
@@ -342,7 +352,8 @@ static inline size_t split_bytes(int64_t m, int64_t k) { return ((size_t)m * 3 *
 // float32 slabs of the k split the plan for m x n x k would use with unlimited workspace
 static size_t slab_bytes(int64_t m, int64_t n, int64_t k) {
     const GemmPlan p = plan_gemm(m, n, k, (size_t)1 << 40);
-    if (const int64_t m1 = tail_split_rows(p, m, n, k, (size_t)1 << 40)) {   // the remainder's k split, if it has one
+    int head_bm = 0;
+    if (const int64_t m1 = tail_split_rows(p, m, n, k, (size_t)1 << 40, &head_bm)) {   // the remainder's k split, if it has one
         const GemmPlan p2 = plan_gemm(m - m1, n, k, (size_t)1 << 40);
         return p2.splits > 1 ? (size_t)p2.splits * (m - m1) * n * sizeof(float) : 0;
     }
