@@ -483,10 +483,10 @@ def test_matmul_matches_reference_forward_golden(ops, dev, golden_dir):
     assert np.max(np.abs(got.cpu().numpy() - g["ternary_randn_y"])) <= 5e-5  # two float32 summation orders at K=256
 
 
-def test_matmul_full_size_4096(ops, dev):
+def test_matmul_full_size_4096(ops, dev, c_oracle):
     """The benchmark configuration, 4096 x 4096 x 4096 f16 on the exact grid: all 16.7M outputs
-    against a float32 matmul of the unpacked weights (exact on this grid, so any correct
-    implementation gives the same bits), plus 64 rows against the CPU oracle."""
+    against the C restatement of the reference op (sums are exact on this grid, so any correct
+    implementation gives the same bits), plus 64 rows against the numpy oracle."""
     g = torch.Generator(device="cpu").manual_seed(1234)
     m = n = k = 4096
     x = (torch.randint(-64, 65, (m, k), generator=g).float() / 64.0)
@@ -495,9 +495,7 @@ def test_matmul_full_size_4096(ops, dev):
     bias = torch.randn(n, generator=g)
     pw = ops.ternarize_pack(w.to(dev))
     y = ops.ternary_matmul(x.to(dev).half(), pw, scale.to(dev), bias.to(dev), 100.0, out_dtype=torch.float32)
-    wt = ops.unpack_ternary(pw, k)
-    acc = x.to(dev) @ wt.t()
-    ref = torch.clip(acc * scale.to(dev) + bias.to(dev), -100.0, 100.0)
+    ref = torch.from_numpy(c_oracle(x.numpy(), pw.cpu().numpy(), scale.numpy(), bias.numpy(), 100.0)).to(dev)   # every output, C restatement
     assert torch.equal(y, ref)
     rows = torch.randint(0, m, (64,), generator=g)
     want = O.ternary_matmul(x[rows].numpy(), pw.cpu().numpy(), scale.numpy(), bias.numpy(), 100.0)
@@ -553,10 +551,10 @@ def test_popcount_invalid_code_and_gelu(ops, dev):
 
 @pytest.mark.parametrize("m,n,k", [(4400, 4200, 192), (5000, 4100, 64), (25216, 768, 128), (2600, 8192, 448)])
 @pytest.mark.parametrize("xdt", [torch.float16, torch.bfloat16, torch.float32])
-def test_matmul_more_tiles_than_cus(ops, dev, m, n, k, xdt):
+def test_matmul_more_tiles_than_cus(ops, dev, c_oracle, m, n, k, xdt):
     """More 256 x 256 output tiles than compute units: one workgroup walks several tiles as one stream of k steps
-    (ragged edges, one to seven steps per tile).  Exact grid, so a float32 matmul of the unpacked weights gives the
-    same bits; a row sample is checked against the CPU oracle."""
+    (ragged edges, one to seven steps per tile).  Exact grid, so the C restatement of the reference op gives the
+    same bits whatever its summation order; a row sample is checked against the numpy oracle too."""
     g = torch.Generator(device="cpu").manual_seed(m + n + k)
     x = torch.randint(-64, 65, (m, k), generator=g).float() / 64.0
     w = torch.rand(n, k, generator=g) * 2 - 1
@@ -564,7 +562,7 @@ def test_matmul_more_tiles_than_cus(ops, dev, m, n, k, xdt):
     bias = torch.randn(n, generator=g)
     pw = ops.ternarize_pack(w.to(dev))
     y = ops.ternary_matmul(x.to(dev).to(xdt), pw, scale.to(dev), bias.to(dev), 100.0, out_dtype=torch.float32)
-    ref = torch.clip((x.to(dev) @ ops.unpack_ternary(pw, k).t()) * scale.to(dev) + bias.to(dev), -100.0, 100.0)
+    ref = torch.from_numpy(c_oracle(x.numpy(), pw.cpu().numpy(), scale.numpy(), bias.numpy(), 100.0)).to(dev)   # every output, C restatement
     assert torch.equal(y, ref)
     rows = torch.randint(0, m, (16,), generator=g)
     want = O.ternary_matmul(x[rows].numpy(), pw.cpu().numpy(), scale.numpy(), bias.numpy(), 100.0)
@@ -574,7 +572,7 @@ def test_matmul_more_tiles_than_cus(ops, dev, m, n, k, xdt):
 
 
 @pytest.mark.parametrize("m,n,k", [(4096, 4096, 64), (4000, 4096, 128), (4096, 3900, 320), (4096, 4096, 576), (3840, 4096, 640), (4096, 3900, 704), (4096, 4096, 768)])
-def test_matmul_one_tile_per_cu_short_k(ops, dev, m, n, k):
+def test_matmul_one_tile_per_cu_short_k(ops, dev, c_oracle, m, n, k):
     """192 .. 256 tiles of 256 x 256, one per compute unit, with one to twelve k steps (every remainder modulo four from nine on, where the planner picks this tile): the four-tile LDS pipeline's
     prologue, its counted waits and its tail (fewer steps than tiles in flight)."""
     g = torch.Generator(device="cpu").manual_seed(m + n + k)
@@ -583,7 +581,7 @@ def test_matmul_one_tile_per_cu_short_k(ops, dev, m, n, k):
     scale = torch.rand(n, generator=g) + 0.5
     bias = torch.randn(n, generator=g)
     pw = ops.ternarize_pack(w.to(dev))
-    ref = torch.clip((x.to(dev) @ ops.unpack_ternary(pw, k).t()) * scale.to(dev) + bias.to(dev), -100.0, 100.0)
+    ref = torch.from_numpy(c_oracle(x.numpy(), pw.cpu().numpy(), scale.numpy(), bias.numpy(), 100.0)).to(dev)   # every output, C restatement
     for xdt in (torch.float16, torch.bfloat16):
         y = ops.ternary_matmul(x.to(dev).to(xdt), pw, scale.to(dev), bias.to(dev), 100.0, out_dtype=torch.float32)
         assert torch.equal(y, ref)
