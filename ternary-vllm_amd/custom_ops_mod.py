@@ -475,6 +475,23 @@ def _vec(v: torch.Tensor, n: int, device, name: str) -> torch.Tensor:
 _F32_DENORM_MIN = 1.401298464324817e-45   # smallest positive float32: (w >= it) is (w > 0), (w <= -it) is (w < 0)
 
 
+_UNIT_SCALES = {}
+
+
+def _unit_scale(n: int, device: torch.device) -> torch.Tensor:
+    """A vector of n ones on `device`, kept between calls (a few sizes at most: every call of ternary_mm would otherwise
+    launch a fill kernel of its own)."""
+    key = (device.type, device.index, n)
+    t = _UNIT_SCALES.get(key)
+    if t is None and torch.cuda.is_current_stream_capturing():   # a tensor born inside a capture belongs to that graph: not kept
+        return torch.ones((n,), dtype=torch.float32, device=device)
+    if t is None:
+        if len(_UNIT_SCALES) >= 32:
+            _UNIT_SCALES.clear()
+        t = _UNIT_SCALES[key] = torch.ones((n,), dtype=torch.float32, device=device)
+    return t
+
+
 def ternary_mm(m: torch.Tensor, tm: torch.Tensor, method: str = "auto") -> torch.Tensor:
     """Multiplication-free select-and-sum with dense weights: ``m @ sign(tm)^T``
     (``matrix_mul_tests.py:29-37``; float32).
@@ -491,12 +508,11 @@ def ternary_mm(m: torch.Tensor, tm: torch.Tensor, method: str = "auto") -> torch
         raise ValueError(f"ternary_mm: inner dimensions differ ({m.shape[1]} vs {tm.shape[1]})")
     if method not in ("auto", "select", "matmul"):
         raise ValueError(f"Unknown ternary_mm method: {method}")
-    if method == "auto":
-        method = "matmul" if m.shape[0] * tm.shape[0] * m.shape[1] >= (1 << 21) else "select"
+    if method == "auto":   # measured (HIP-graph replay, us): 64^3 select 18.3 / matmul 9.7, 256^3 68 / 14.8, 1024^3 313 / 32.7
+        method = "matmul" if m.shape[0] * tm.shape[0] * m.shape[1] >= (1 << 16) else "select"
     if method == "matmul":
         pw = ternarize_pack(tm, _F32_DENORM_MIN)
-        ones = torch.ones((tm.shape[0],), dtype=torch.float32, device=m.device)
-        return ternary_matmul(m, pw, ones, None, float("inf"))
+        return ternary_matmul(m, pw, _unit_scale(tm.shape[0], m.device), None, float("inf"))
     res = torch.empty((m.shape[0], tm.shape[0]), dtype=torch.float32, device=m.device)
     with torch.cuda.device(m.device):
         _check(_lib.tvl_ternary_mm_f32(m.data_ptr(), m.shape[0], m.shape[1], _ld(m), tm.data_ptr(), tm.shape[0], _ld(tm),

@@ -2,7 +2,7 @@
 // shader-clock (s_memtime) and 100 MHz (s_memrealtime) stamps at entry, around the k loop and after the epilogue, runs back-to-back
 // launches on random data for ~2 s and prints, as medians over workgroups of the LAST launch: the clock held over the k loop,
 // cycles and microseconds of prologue / loop / epilogue, cycles per 64-deep k step.
-//   usage: gemm_clock [wide=0|1] [M N K]
+//   usage: gemm_clock [form=0|1|2] [M N K [splits]]   (0: the shipped 256 x 256 tile, 1: four waves x 64 channels, 2: 128 x 128 split-K)
 #define TVL_CLOCK_PROBE 1
 #include "../../ternary-vllm_amd/csrc/gemm_mfma_kernels.h"
 
@@ -16,6 +16,40 @@ using namespace tvl;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
+
+// the mid-size path's split-K form: 128 x 128 tiles of four waves, `splits` k ranges per tile, raw float32 partial sums to slabs
+static void run_mid_split(int m, int n, int k, int splits, const f16* x, const uint8_t* pw, const float* sc, const float* bi, float* slab) {
+    constexpr int NB = 4;
+    auto kern = gemm_mfma16_kernel<f16, float, false, TVL_ACT_NONE, 1, false, NB, 128, 4, true, 3>;
+    const size_t lds = (size_t)NB * 128 * ROW_BYTES;
+    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int tiles_n = (n + 127) / 128, nblk = ((m + 127) / 128) * tiles_n, per = (k / 64 + splits - 1) / splits;
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    float ms = 0;
+    for (int round = 0; round < 8; ++round) {
+        CHECK(hipEventRecord(a, 0));
+        for (int i = 0; i < 5000; ++i)
+            hipLaunchKernelGGL(kern, dim3(nblk, splits), dim3(256), lds, 0, x, m, k, (int64_t)k, pw, n, (int64_t)(k / 4), sc, bi, 100.0f, 0, slab, (int64_t)n,
+                               tiles_n, nblk, k / 64, per);
+        CHECK(hipEventRecord(b, 0)); CHECK(hipEventSynchronize(b));
+        CHECK(hipEventElapsedTime(&ms, a, b));
+    }
+    std::vector<unsigned long long> h(8 * 4096);
+    CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(tvl_clock_probe), h.size() * 8));
+    std::vector<double> ghz, pro_us, loop_us, epi_us, all_us, loopc;
+    unsigned long long r_first = ~0ull, r_last = 0;
+    for (int bl = 0; bl < std::min(nblk, 4096); ++bl) {   // the stamps of the blockIdx.y == 0 workgroups
+        const unsigned long long* c = &h[8 * bl]; const unsigned long long* r = c + 4;
+        ghz.push_back((double)(c[2] - c[1]) / (double)(r[2] - r[1]) * 0.1); loopc.push_back((double)(c[2] - c[1]));
+        pro_us.push_back((r[1] - r[0]) * 0.01); loop_us.push_back((r[2] - r[1]) * 0.01); epi_us.push_back((r[3] - r[2]) * 0.01);
+        all_us.push_back((r[3] - r[0]) * 0.01);
+        r_first = std::min(r_first, r[0]); r_last = std::max(r_last, r[3]);
+    }
+    printf("128 x 128 tiles, %d tiles x %d k ranges of %d steps: %.2f us per launch (event pair)\n", nblk, splits, per, ms / 5000 * 1e3);
+    printf("  clock over the k loop %.3f GHz   prologue %.2f us   k loop %.2f us (%.0f cyc per step)   epilogue (slab stores) %.2f us   workgroup lifetime %.2f us\n",
+           med(ghz), med(pro_us), med(loop_us), med(loopc) / per, med(epi_us), med(all_us));
+    printf("  first workgroup entry to last workgroup exit (k range 0 only): %.2f us\n", (r_last - r_first) * 0.01);
+}
 
 template <int WAVES, int WN, int MINW>
 static void run(int m, int n, int k, const f16* x, const uint8_t* pw, const float* sc, const float* bi, f16* y) {
@@ -76,6 +110,12 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&sc, n * 4)); CHECK(hipMalloc(&bi, n * 4));
     CHECK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CHECK(hipMemcpy(pw, hw.data(), hw.size(), hipMemcpyHostToDevice));
     CHECK(hipMemcpy(sc, hs.data(), n * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(bi, hb.data(), n * 4, hipMemcpyHostToDevice));
+    if (wide == 2) {   // gemm_clock 2 M N K splits
+        const int splits = argc > 5 ? atoi(argv[5]) : 4;
+        float* slab; CHECK(hipMalloc(&slab, (size_t)splits * m * n * 4));
+        run_mid_split(m, n, k, splits, x, pw, sc, bi, slab);
+        return 0;
+    }
     if (wide) run<4, 64, 1>(m, n, k, x, pw, sc, bi, y);
     else run<8, 32, 2>(m, n, k, x, pw, sc, bi, y);
     return 0;
