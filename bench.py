@@ -426,6 +426,12 @@ def main():
                             "GBps": round(d_bytes / (d_avg * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(d_bytes / (d_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                 del pwd
 
+            # the cost of one kernel node of a replayed HIP graph (a 64-element zero_out): the floor under every short launch above
+            tiny = torch.zeros(64, dtype=torch.int32, device=dev)
+            f_avg, _, f_how = time_graph(lambda i: ops.zero_out(tiny), 50, 5)
+            hbm["graph_node_floor"] = {"avg_call_ms": round(f_avg, 5), "timing": f_how,
+                                       "note": "one empty-ish kernel per graph node: launch-bound points (decode_m1, rows16, rows64 at 4096^2) sit on this floor plus their own work"}
+
             # ---- the vendor's dense f16 GEMM (hipBLASLt through torch.matmul) on the same shape, buffers and pre-warm: a yardstick
             wd = ops.unpack_ternary(pw, K, dtype=torch.float16)
             for i in range(PREWARM):
