@@ -170,9 +170,9 @@ struct GemmPlan { int kind, bm, bn, splits; double us; };   // us: modelled time
 // share a CU.  Measured with TVL_FORCE_PLAN over M = 256 .. 4096 at N = K = 4096 and the moondream prefill shapes.
 struct TileCost { int kind, bm, bn, occupancy; double fixed_us, step_light_us, step_full_us, step_shared_us; };
 static const TileCost TILE_COSTS[] = {
-    {KIND_BIG, 256, 256, 1, 14.0, 1.20, 1.57, 1.57},    // 8 waves, 96 / 128 KiB LDS
+    {KIND_BIG, 256, 256, 1, 14.0, 1.20, 1.40, 1.57},    // 8 waves, 96 / 128 KiB LDS (shared = a step of the persistent form: three LDS tiles)
     {KIND_MID, 128, 256, 1, 7.0, 0.62, 0.84, 0.84},     // 8 waves, 64 KiB LDS
-    {KIND_MID, 128, 128, 2, 6.0, 0.42, 0.47, 0.49},     // 4 waves, 64 KiB LDS
+    {KIND_MID, 128, 128, 2, 6.0, 0.42, 0.50, 0.49},     // 4 waves, 64 KiB LDS
     {KIND_MID, 64, 128, 4, 5.0, 0.28, 0.36, 0.30},      // 4 waves, 32 KiB LDS
     {KIND_SMALL, 32, 128, 3, 4.0, 0.21, 0.21, 0.21},
 };
@@ -205,22 +205,34 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_byte
     double best_t = 1e30;
     for (const TileCost& tc : TILE_COSTS) {
         if (tc.bm > 32 && m <= tc.bm / 2) continue;   // more than half of the tile's rows would be padding
-        // few rows per decoded weight: only where taller tiles would be mostly padding - or, up to 256 rows, on small layers, where
-        // twice the tiles fill the chip with half the k split (256 x 2048 x 2048: 16.1 -> 13.8 us; larger layers lose)
-        if ((tc.bm == 64 && m > 192 && !(m <= 256 && n * k <= ((int64_t)1 << 23))) || (tc.bm == 32 && m > 48)) continue;
+        if (tc.bm == 32 && m > 48) continue;          // two row tiles per decoded weight: only where taller tiles would be mostly padding
         const int64_t tiles = ceil_div(m, tc.bm) * ceil_div(n, tc.bn);
         for (int64_t s = 1; s <= 64; ++s) {
             if (s > 1 && (s > max_by_ws || steps / s < 2 || tc.kind == KIND_BIG)) break;
             const int64_t per = ceil_div(steps, s);
             const int64_t q = ceil_div(tiles * s, cus);
             const double load = (double)(tiles * s) / (double)cus;
-            double t = (double)ceil_div(q, tc.occupancy) * tc.fixed_us +
-                       (double)per * (q == 1 ? (load <= 0.6 ? tc.step_light_us : tc.step_full_us) : (double)q * tc.step_shared_us);
+            // one workgroup per CU: a step costs between its time on a lightly loaded chip (half of the CUs busy) and on a full one
+            const double fill = load <= 0.5 ? 0.0 : (load >= 1.0 ? 1.0 : (load - 0.5) / 0.5);
+            const double step1 = tc.step_light_us + (tc.step_full_us - tc.step_light_us) * fill;
+            // the big tile's fixed part is mostly its 128 KiB-per-tile store burst: it grows with the number of tiles that end together
+            const double fixed1 = tc.kind == KIND_BIG ? tc.fixed_us - 4.0 * (1.0 - (load < 1.0 ? load : 1.0)) : tc.fixed_us;
+            double t = q == 1 ? fixed1 + (double)per * step1
+                              : (double)ceil_div(q, tc.occupancy) * tc.fixed_us + (double)per * (double)q * tc.step_shared_us;
             // the 256 x 256 tile walks its q tiles per CU as one stream of k steps: the fixed cost once, ~4 us of epilogue per tile
-            if (tc.kind == KIND_BIG && q > 1) t = tc.fixed_us + (double)q * ((double)per * tc.step_full_us + 4.0);
-            // so does the 128 x 256 tile (gemm_mid.hip), at ~6 us per tile for its epilogue under the next tile's first steps
-            if (tc.kind == KIND_MID && tc.bn == 256 && s == 1 && tiles > cus) t = tc.fixed_us + load * ((double)per * 0.9 + 6.0);
+            if (tc.kind == KIND_BIG && q > 1) t = tc.fixed_us + (double)q * ((double)per * tc.step_shared_us + 4.0);
+            // so does the 128 x 256 tile (gemm_mid.hip): whole rounds of k loops, the last one maybe on a lightly loaded chip, and ~6 us
+            // per tile for its epilogue under the next tile's first steps
+            if (tc.kind == KIND_MID && tc.bn == 256 && s == 1 && tiles > cus) {
+                const int64_t rounds = ceil_div(tiles, cus);
+                const double last = load - (double)(rounds - 1);
+                t = tc.fixed_us + (double)(rounds - 1) * (double)per * tc.step_full_us +
+                    (double)per * (last <= 0.6 ? tc.step_light_us : tc.step_full_us) + load * 6.0;
+            }
             if (s > 1) t += 3.0 + 3.0 * (double)s * (double)m * (double)n * 4.0 / 8.0e6;
+            // 64-row tiles beyond 192 rows decode every weight for four row tiles only: they win where taller tiles leave the chip
+            // half empty or need a k split (512 x 2048 x 2048: 18.7 -> 14.5 us); a small handicap settles the near-ties the other way
+            if (tc.bm == 64 && m > 192) t *= 1.03;
             if (t < best_t) { best_t = t; best = GemmPlan{tc.kind, tc.bm, tc.bn, (int)s, t}; }
         }
     }
@@ -246,7 +258,7 @@ static int64_t tail_split_rows(const GemmPlan& p, int64_t m, int64_t n, int64_t 
         if (m1 <= 0 || m1 >= m) continue;
         // the cost table's rows of these two tiles: one k loop per round, the epilogue under the next tile's first steps
         const TileCost& tc = TILE_COSTS[bm == 256 ? 0 : 1];
-        const double t1 = bm == 256 ? (rounds == 1 ? tc.fixed_us + per * tc.step_full_us : tc.fixed_us + (double)rounds * (per * tc.step_full_us + 4.0))
+        const double t1 = bm == 256 ? (rounds == 1 ? tc.fixed_us + per * tc.step_full_us : tc.fixed_us + (double)rounds * (per * tc.step_shared_us + 4.0))
                                     : (rounds == 1 ? tc.fixed_us + per * tc.step_full_us : tc.fixed_us + (double)rounds * (per * 0.9 + 6.0));
         const double t = t1 + plan_gemm(m - m1, n, k, workspace_bytes).us + 2.0;
         if (t < best_t) { best_t = t; best_m1 = m1; *head_bm = bm; }
