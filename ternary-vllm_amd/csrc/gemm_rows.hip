@@ -706,11 +706,16 @@ bool gemm_rows_shared_supported(const void* x, int x_dtype, int64_t m, int64_t k
     // 14336 x 2048, 17.1 -> 10.7 at 4096 x 8192, 19.1 -> 12.8 at 8192^2, 39 -> 29 at 16384^2, but 8.5 -> 9.2 at 4096^2; at 48
     // rows 42 -> 21 at 8192^2; at 64 rows the 64-row matrix-core tile keeps 8192^2 (20.5 against 22.5) and loses 16384^2 (60 -> 52).
     const double weights = (double)n * (double)k;
-    const double need = m <= 16 ? (k >= 8192 ? 1.5e7 : 2.0e7) : (m <= 32 ? 2.5e7 : (m <= 48 ? 3.0e7 : 2.0e8));
+    // (33 .. 48 rows: from 1.2e7 weights on, where the alternative is a 64-row matrix-core tile with a k split - 40 x 6144 x 2048: 17.0 -> 12.4,
+    // 48 x 14336 x 2048: 18.2 -> 15.2; 49 .. 64 rows: from 1e8 on - 64 x 28672 x 4096: 32.8 -> 26.0, while 64 x 8192^2 stays with the tile)
+    const double need = m <= 16 ? (k >= 8192 ? 1.5e7 : 2.0e7) : (m <= 32 ? 2.5e7 : (m <= 48 ? 1.2e7 : 1.0e8));
     if (weights < need) return false;
     const SharedPlan p = plan_rows_shared(m, n, k, (workspace && aligned(workspace, 16)) ? workspace_bytes : 0);
     // without the workspace for its k split the grid would underfill the chip: leave the shape to the other kernels
-    return p.splits * ceil_div(n, 128) * 2 >= device_cu_count();
+    // (with at most two k ranges three eighths of the chip are enough: 40 x 6144 x 2048 runs 96 workgroups and still beats the 64-row tile +
+    // reduce, 12.4 against 17.0 us; 40 x 3072 x 4096, the same 96 workgroups over four k ranges, loses 13.0 against 12.3)
+    const int64_t wgs = p.splits * ceil_div(n, 128);
+    return wgs * 2 >= device_cu_count() || (p.splits <= 2 && wgs * 8 >= device_cu_count() * 3);
 }
 
 template <typename TX, int MR, int CS>
