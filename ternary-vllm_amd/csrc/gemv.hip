@@ -15,6 +15,8 @@
 #include "tvl_common.h"
 #include "tvl_kernels.h"
 
+#include <stdlib.h>
+
 namespace tvl {
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -178,9 +180,10 @@ __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__
     }
 }
 
-// Chosen against the two-launch split-K kernels by measured cost (microseconds; W = n * k / 1e6): this kernel
-// ~ 2.5 + W * (0.045 + 0.0255 m) (x 1.4 in the 2-channels-per-wave geometry), the streaming kernel + reduce
-// ~ 6 + 0.0735 W.  One or two rows, or a small layer: this kernel.
+// Chosen against the two-launch split-K kernels by measured cost (microseconds; W = n * k / 1e6; tools/gemv_audit.sh times the library's
+// choice beside this kernel switched off / forced): this kernel ~ 2.5 + W * (0.045 + 0.0255 m) * g with g = 1.4 / 1.3 / 0.92 for its three
+// launch geometries, the alternatives as fitted below.  One row: always this kernel; two rows: except on layers of 16 384 channels and
+// more with a short k (2 x 28672 x 4096: 16.2 against 14.5 us).  TVL_GEMV=0 / 2 switches it off / on wherever it can run (tuning).
 bool gemv_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw) {
     if (x_dtype != TVL_F16 && x_dtype != TVL_BF16 && x_dtype != TVL_F32) return false;
     if (m < 1 || m > 4 || k <= 0 || k % 32 != 0) return false;
@@ -188,11 +191,19 @@ bool gemv_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld
     if (!aligned(x, 16) || (ld_x * esz) % 16 != 0) return false;
     if (!aligned(pw, 8) || ld_pw % 8 != 0) return false;
     if (n > INT32_MAX / 2 || k > INT32_MAX) return false;
+    static const int mode = [] { const char* e = getenv("TVL_GEMV"); return e ? atoi(e) : 1; }();   // tuning: 0 = off, 2 = wherever it can run
+    if (mode == 0) return false;
+    if (mode == 2) return true;
     const double w = (double)n * (double)k / 1.0e6;
     const double per = x_dtype == TVL_F32 ? 0.045 + 0.05 * m : 0.045 + 0.0255 * m;
-    const double t_gemv = 2.5 + w * per * (n < 16384 ? 1.4 : 1.0);
-    const double t_other = x_dtype == TVL_F32 ? 25.0 + 0.2 * w     // plane split + bf16 GEMM over 3K on 32-row tiles
-                                               : 6.0 + 0.0735 * w;  // streaming kernel + reduce launch
+    // by launch geometry (launch_gemv_xy): 2 channels per wave on small layers, one-wave blocks of 8 channels, 4-wave blocks that split k
+    const double geom = n < 16384 ? 1.4 : (k >= 8192 ? 0.92 : 1.3);
+    const double t_gemv = 2.5 + w * per * geom;
+    // the alternatives for one or two rows, fitted to tools/gemv_audit.sh: float32 = plane split + bf16 GEMM over 3K on 32-row tiles; bf16 = the
+    // register-streaming kernel + reduce launch; f16 = the LDS-ring streaming kernel + reduce launch
+    const double t_other = x_dtype == TVL_F32 ? 25.0 + 0.2 * w
+                         : x_dtype == TVL_BF16 ? 9.7 + 0.09 * w
+                         : (w <= 70.0 ? 8.5 + 0.085 * w : (6.2 + 0.071 * w > 14.3 ? 6.2 + 0.071 * w : 14.3));
     return t_gemv <= t_other;
 }
 
