@@ -183,8 +183,9 @@ bool gemm_rows_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64
     if (n > INT32_MAX - 64 || k > INT32_MAX) return false;
     if (x_dtype == TVL_F32) return aligned(x, 16) && (ld_x * 4) % 16 == 0 && rows_f32_planes_ok(m, n, k, workspace, workspace_bytes);
     if (x_dtype != TVL_F16 && x_dtype != TVL_BF16) return false;
-    if (m < 3 || m > 32 || k <= 0 || k % 256 != 0) return false;
+    if (m < 3 || m > 64 || k <= 0 || k % 256 != 0) return false;
     if (!aligned(x, 16) || (ld_x * 2) % 16 != 0) return false;
+    if (m > 32) return rows_use_staged(m, n, k);   // 33 .. 64 rows: only the staged form
     const double work = (double)m * (double)n * (double)k;
     if (rows_use_staged(m, n, k)) return true;
     return m <= 16 ? work <= 3.0e8 : (double)n * (double)k <= 4.2e6;
@@ -242,17 +243,19 @@ int launch_gemm_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t l
     return launch_rows_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, st);
 }
 
-// LDS of one workgroup: the image of one phase (at most 8 * SPW steps), reused for the partial sums
+// LDS of one workgroup: the image of one phase (at most 8 * SPW steps; 4 steps with 3 or 4 row blocks, where the waves also split the
+// channel tiles), reused for the partial sums
 static size_t rows_staged_lds_bytes(int mr, int ct, int64_t k) {
-    const int64_t steps = k / 256, spw = (mr == 1 && k > 2048) ? 2 : 1, phase_steps = steps < 8 * spw ? steps : 8 * spw;
-    const size_t image = (size_t)phase_steps * mr * 8 * 65 * 16, sums = (size_t)8 * mr * ct * 64 * 16;
+    const int64_t steps = k / 256, spw = (mr == 1 && k > 2048) ? 2 : 1, ps = mr > 2 ? 4 : 8 * spw, phase_steps = steps < ps ? steps : ps;
+    const size_t image = (size_t)phase_steps * mr * 8 * 65 * 16, sums = (size_t)8 * mr * (mr > 2 ? ct / 2 : ct) * 64 * 16;
     return image > sums ? image : sums;
 }
-// 16-channel tiles per workgroup: 1 while one round of workgroups covers n, else 2, 4 or 8 (two phases at 17 .. 32 rows: 1)
+// 16-channel tiles per workgroup: 1 while one round of workgroups covers n, else 2, 4 or 8 (two phases at 17 .. 32 rows: 1; 33 .. 64 rows: 2 or 4,
+// the waves splitting them)
 static int rows_staged_tiles(int64_t m, int64_t n, int64_t k) {
+    if (m > 32) return ceil_div(n, 32) <= (int64_t)device_cu_count() ? 2 : 4;
     const int mr = m <= 16 ? 1 : 2;
     if (mr == 2 && k > 2048) return 1;
-    // (measured beyond these: 16 x 16384 x 8192 with 4 tiles 17.4 -> 17.8 us, 16 x 28672 x 4096 with 8 tiles 14.5 -> 16.6: not used)
     // (measured beyond these: 16 x 16384 x 8192 with 4 tiles 17.4 -> 17.8 us, 16 x 28672 x 4096 with 8 tiles 14.5 -> 16.6: not used)
     const int max_ct = mr == 1 ? (k > 4096 ? 2 : (k > 2048 ? 4 : 8)) : 4;
     for (int ct = 1; ct < max_ct; ct *= 2) {
@@ -272,16 +275,21 @@ static int rows_staged_tiles(int64_t m, int64_t n, int64_t k) {
 // gemm_rows_shared_kernel), its weight loads - issued AFTER the activation loads, so that waiting for the latter leaves them in
 // flight - arriving meanwhile.  Then every wave multiplies its steps out of LDS (the second phase's activations travelling in
 // registers meanwhile) and the partial sums are added through LDS in wave order as above.
-template <typename TX, int MR, int CT, int SPW, int PH>   // CT: 16-channel tiles per workgroup; SPW: steps per wave and phase; PH: phases
+// TW = 2 (33 .. 64 rows: three or four 16-row blocks): an image of 8 steps would not fit, so a phase is 4 steps and the waves form two
+// groups that split the workgroup's channel tiles - wave = (tile group, step of the phase).
+template <typename TX, int MR, int CT, int SPW, int PH, int TW = 1>   // CT: 16-channel tiles per workgroup; SPW: steps per wave and phase; PH: phases
 __global__ void __launch_bounds__(512)
 gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uint8_t* __restrict__ pw, int n, int64_t ld_pw,
                         const float* __restrict__ scale, const float* __restrict__ bias, float clip, int act, int act_begin, void* __restrict__ y,
                         int y_dtype, int64_t ld_y, int planes) {
-    constexpr int WAVES = 8, FS = 65, IMG = 8 * FS, PS = WAVES * SPW;   // PS: steps per phase (k <= 256 * PS * PH)
+    constexpr int WAVES = 8, FS = 65, IMG = 8 * FS;
+    constexpr int SW = WAVES / TW, CTW = CT / TW, PS = SW * SPW;   // SW waves along the steps of a phase, CTW tiles per wave, PS steps per phase (k <= 256 * PS * PH)
+    static_assert(CT % TW == 0 && (TW == 1 || TW == 2), "the waves split the channel tiles evenly");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4* xbuf = reinterpret_cast<uint4*>(lds_raw);                 // [steps of one phase][MR][8 fragments][FS]
-    floatx4* red = reinterpret_cast<floatx4*>(lds_raw);              // [WAVES][MR * CT][64], over the image once it has been read
+    floatx4* red = reinterpret_cast<floatx4*>(lds_raw);              // [WAVES][MR * CTW][64], over the image once it has been read
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sw = wave % SW, tg = wave / SW;                         // this wave's step slot inside a phase and its tile group
     const int c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * (16 * CT);
     const int total = k / 256;
@@ -315,18 +323,18 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
             for (int i = 0; i < MR; ++i) *reinterpret_cast<nts_u32x4*>(xbuf + (s * MR + i) * IMG + st_dst) = st[s][i];
     };
     load_phase(0);
-    // ---- weight loads of all of this wave's steps: step ph * PS + wave * SPW + q (past the end: the last step again, never used)
-    uint4 w[PH][SPW][CT];
+    // ---- weight loads of all of this wave's steps: step ph * PS + sw * SPW + q (past the end: the last step again, never used)
+    uint4 w[PH][SPW][CTW];
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        int gn = n0 + 16 * t + c;
+    for (int t = 0; t < CTW; ++t) {
+        int gn = n0 + 16 * (tg * CTW + t) + c;
         gn = gn < n ? gn : n - 1;
         const uint4* wp = reinterpret_cast<const uint4*>(pw + (int64_t)gn * ld_pw + 16 * g);
 #pragma unroll
         for (int ph = 0; ph < PH; ++ph)
 #pragma unroll
             for (int q = 0; q < SPW; ++q) {
-                int s = ph * PS + wave * SPW + q;
+                int s = ph * PS + sw * SPW + q;
                 s = s < total ? s : total - 1;
                 const nts_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nts_u32x4*>(wp + (int64_t)s * 4));
                 w[ph][q][t] = make_uint4(v[0], v[1], v[2], v[3]);
@@ -335,35 +343,41 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
     store_phase();
     __syncthreads();
 
-    floatx4 acc[MR][CT];
+    floatx4 acc[MR][CTW];
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
-        for (int t = 0; t < CT; ++t) acc[i][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < CTW; ++t) acc[i][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
     const DecodeConsts dc = make_decode_consts();
+    constexpr int JB = MR > 2 ? 4 : 8;   // fragments read ahead of the multiplication (three or four row blocks: half a step, 64 registers)
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph) {
         if (ph < nph) {
             if (ph + 1 < PH && ph + 1 < nph) load_phase(ph + 1);      // the next phase's activations travel while this one is multiplied
 #pragma unroll
             for (int q = 0; q < SPW; ++q) {
-                if (ph * PS + wave * SPW + q < total) {
-                    const uint4* img = xbuf + (wave * SPW + q) * MR * IMG + lane;
-                    uint4 xf[8][MR];
+                if (ph * PS + sw * SPW + q < total) {
+                    const uint4* img = xbuf + (sw * SPW + q) * MR * IMG + lane;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                    for (int jb = 0; jb < 8; jb += JB) {
+                        uint4 xf[JB][MR];
 #pragma unroll
-                        for (int i = 0; i < MR; ++i) xf[j][i] = img[i * IMG + j * FS];
+                        for (int j = 0; j < JB; ++j)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                            for (int i = 0; i < MR; ++i) xf[j][i] = img[i * IMG + (jb + j) * FS];
 #pragma unroll
-                        for (int t = 0; t < CT; ++t) {
-                            const uint4 wq = w[ph][q][t];
-                            const uint32_t d = (j >> 1) == 0 ? wq.x : (j >> 1) == 1 ? wq.y : (j >> 1) == 2 ? wq.z : wq.w;
-                            const uint4 a = (j & 1) ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc);
+                        for (int jj = 0; jj < JB; ++jj) {
+                            const int j = jb + jj;
 #pragma unroll
-                            for (int i = 0; i < MR; ++i) acc[i][t] = mfma16<TX>(a, xf[j][i], acc[i][t]);
+                            for (int t = 0; t < CTW; ++t) {
+                                const uint4 wq = w[ph][q][t];
+                                const uint32_t d = (j >> 1) == 0 ? wq.x : (j >> 1) == 1 ? wq.y : (j >> 1) == 2 ? wq.z : wq.w;
+                                const uint4 a = (j & 1) ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc);
+#pragma unroll
+                                for (int i = 0; i < MR; ++i) acc[i][t] = mfma16<TX>(a, xf[jj][i], acc[i][t]);
+                            }
                         }
+                    }
                 }
             }
             if (ph + 1 < PH && ph + 1 < nph) {
@@ -377,11 +391,11 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
-        for (int t = 0; t < CT; ++t) red[(wave * MR * CT + i * CT + t) * 64 + lane] = acc[i][t];
+        for (int t = 0; t < CTW; ++t) red[(wave * MR * CTW + i * CTW + t) * 64 + lane] = acc[i][t];
     __syncthreads();
     const float cl = fabsf(clip);
     const bool has_bias = bias != nullptr;
-    if (planes == 3) {
+    if (TW == 1 && planes == 3) {
         // float32 activations arrive as three bf16 planes in row blocks: rows r, m/3 + r, 2m/3 + r of the product are one output row
         const int mo = m / 3;
         for (int t = wave; t < CT; t += WAVES) {
@@ -399,20 +413,21 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
         }
         return;
     }
-    for (int f = wave; f < MR * CT; f += WAVES) {
-        const int i = f / CT, t = f % CT;
-        floatx4 s = red[f * 64 + lane];
+    for (int f = wave; f < MR * CT; f += WAVES) {   // output fragment (row block i, tile T): the partial sums of tile group T / CTW, in wave order
+        const int i = f / CT, T = f % CT;
+        const floatx4* src = red + (((T / CTW) * SW) * MR * CTW + i * CTW + T % CTW) * 64 + lane;
+        floatx4 s = src[0];
 #pragma unroll
-        for (int ww = 1; ww < WAVES; ++ww) s += red[(ww * MR * CT + f) * 64 + lane];
-        rows_store_fragment(s, 16 * i + c, n0 + 16 * t + 4 * g, m, n, scale, bias, has_bias, act, cl, act_begin, y, y_dtype, ld_y);
+        for (int ww = 1; ww < SW; ++ww) s += src[ww * MR * CTW * 64];
+        rows_store_fragment(s, 16 * i + c, n0 + 16 * T + 4 * g, m, n, scale, bias, has_bias, act, cl, act_begin, y, y_dtype, ld_y);
     }
 }
 
-template <typename TX, int MR, int CT, int SPW, int PH>
+template <typename TX, int MR, int CT, int SPW, int PH, int TW = 1>
 static int launch_rows_staged_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                                   const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, int planes, hipStream_t st) {
     const size_t lds_bytes = rows_staged_lds_bytes(MR, CT, k);
-    auto kern = gemm_rows_staged_kernel<TX, MR, CT, SPW, PH>;
+    auto kern = gemm_rows_staged_kernel<TX, MR, CT, SPW, PH, TW>;
     if (int rc = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc != TVL_OK) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(n, 16 * CT)), dim3(512), lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip,
                        act, act_begin, y, y_dtype, ld_y, planes);
@@ -424,6 +439,14 @@ template <typename TX>
 static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                                 const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, int planes, hipStream_t st) {
     const int ct = rows_staged_tiles(m, n, k);
+    if (m > 32) {   // 33 .. 64 rows, k <= 2048: three or four row blocks, phases of 4 steps, the waves split 2 or 4 channel tiles
+#define TVL_STAGED_TW(MR, CT) \
+    return launch_rows_staged_cfg<TX, MR, CT, 1, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, planes, st)
+        if (m <= 48) { if (ct == 2) TVL_STAGED_TW(3, 2); TVL_STAGED_TW(3, 4); }
+        if (ct == 2) TVL_STAGED_TW(4, 2);
+        TVL_STAGED_TW(4, 4);
+#undef TVL_STAGED_TW
+    }
 #define TVL_STAGED(MR, CT, SPW, PH) \
     return launch_rows_staged_cfg<TX, MR, CT, SPW, PH>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, planes, st)
 #define TVL_STAGED_CT(MR, SPW, PH)                   \
@@ -451,11 +474,19 @@ static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x,
 // 16 x 4096^2 8.4 -> 5.9, 16 x 2048^2 5.1 -> 3.7, 16 x 6144 x 2048 9.3 -> 5.8, 8 x 4096^2 6.4 -> 5.7, 32 x 2048^2 8.0 -> 5.35,
 // 32 x 4096^2 10.8 -> 8.4; against the shared-activation kernel 16 x 14336 x 2048 9.4 -> 6.8, 16 x 8192 x 4096 10.5 -> 7.9,
 // 32 x 8192 x 2048 10.4 -> 6.6, 16 x 14336 x 4096 11.7 -> 10.8, but 16 x 32000 x 1024 6.7 -> 7.5; 4 x 6144 x 2048 6.2 -> 5.0.
+// 33 .. 64 rows with k <= 2048 (three or four row blocks, phases of 4 steps, the waves split 2 or 4 channel tiles; one round of workgroups, so
+// n <= 16384): 64 x 2048^2 10.5 -> 8.8, 64 x 6144 x 2048 13.0 -> 9.5, 64 x 14336 x 2048 14.5 -> 12.1, 48 x 14336 x 2048 15.2 -> 10.5,
+// 40 x 6144 x 2048 12.3 -> 8.0, 64 x 1024^2 7.9 -> 5.5 against the 64-row matrix-core tile + reduce / the shared-activation kernel.
 // TVL_ROWS_STAGED=0 turns it off (tuning), 2 lifts the size rules (tests).
 static bool rows_use_staged(int64_t m, int64_t n, int64_t k) {
     static const int mode = [] { const char* e = getenv("TVL_ROWS_STAGED"); return e ? atoi(e) : 1; }();   // 2: whatever fits (tests)
-    if (m > 32 || k > (m <= 16 ? 8192 : 4096)) return false;
+    if (m > 64 || k > (m <= 16 ? 8192 : (m <= 32 ? 4096 : 2048))) return false;
+    if (m > 32 && n < 32) return false;     // the waves of that form split at least two channel tiles
     if (mode == 2) return true;
+    if (m > 32) {   // one round of workgroups (one per CU: 133 KiB of LDS) on two or four tiles each
+        if (mode == 0) return false;
+        return (double)n * (double)k >= 1.0e6 && ceil_div(n, 64) <= (int64_t)device_cu_count();
+    }
     const double weights = (double)n * (double)k;
     if (mode == 0 || m < 3 || weights < 1.0e6) return false;
     if (k <= 1024 && weights >= 2.0e7) return false;
