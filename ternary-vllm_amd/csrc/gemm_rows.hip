@@ -440,11 +440,16 @@ static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x,
                                 const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y, int planes, hipStream_t st) {
     const int ct = rows_staged_tiles(m, n, k);
     if (m > 32) {   // 33 .. 64 rows, k <= 2048: three or four row blocks, phases of 4 steps, the waves split 2 or 4 channel tiles
-#define TVL_STAGED_TW(MR, CT) \
-    return launch_rows_staged_cfg<TX, MR, CT, 1, 2, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, planes, st)
-        if (m <= 48) { if (ct == 2) TVL_STAGED_TW(3, 2); TVL_STAGED_TW(3, 4); }
-        if (ct == 2) TVL_STAGED_TW(4, 2);
-        TVL_STAGED_TW(4, 4);
+#define TVL_STAGED_TW(MR, CT, PH) \
+    return launch_rows_staged_cfg<TX, MR, CT, 1, PH, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, planes, st)
+        if (k <= 2048) {
+            if (m <= 48) { if (ct == 2) TVL_STAGED_TW(3, 2, 2); TVL_STAGED_TW(3, 4, 2); }
+            if (ct == 2) TVL_STAGED_TW(4, 2, 2);
+            TVL_STAGED_TW(4, 4, 2);
+        }
+        if (m <= 48) { if (ct == 2) TVL_STAGED_TW(3, 2, 4); TVL_STAGED_TW(3, 4, 4); }   // k <= 4096: four phases
+        if (ct == 2) TVL_STAGED_TW(4, 2, 4);
+        TVL_STAGED_TW(4, 4, 4);
 #undef TVL_STAGED_TW
     }
 #define TVL_STAGED(MR, CT, SPW, PH) \
@@ -480,11 +485,14 @@ static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x,
 // TVL_ROWS_STAGED=0 turns it off (tuning), 2 lifts the size rules (tests).
 static bool rows_use_staged(int64_t m, int64_t n, int64_t k) {
     static const int mode = [] { const char* e = getenv("TVL_ROWS_STAGED"); return e ? atoi(e) : 1; }();   // 2: whatever fits (tests)
-    if (m > 64 || k > (m <= 16 ? 8192 : (m <= 32 ? 4096 : 2048))) return false;
+    if (m > 64 || k > (m <= 16 ? 8192 : 4096)) return false;   // (17 .. 32 rows in four phases up to k = 8192: built, 12.4 - 13.9 us against 9.0 - 13.1 without)
     if (m > 32 && n < 32) return false;     // the waves of that form split at least two channel tiles
     if (mode == 2) return true;
     if (m > 32) {   // one round of workgroups (one per CU: 133 KiB of LDS) on two or four tiles each
         if (mode == 0) return false;
+        // four phases (k > 2048) pay on wide layers only: 40 x 8192 x 4096 15.0 -> 13.0, 64 x 14336 x 4096 22.2 -> 19.0, but 40 x 2048 x 4096 10.7 -> 12.1,
+        // 64 x 8192 x 4096 13.6 -> 15.9
+        if (k > 2048 && n < (m <= 48 ? 4096 : 10000)) return false;
         return (double)n * (double)k >= 1.0e6 && ceil_div(n, 64) <= (int64_t)device_cu_count();
     }
     const double weights = (double)n * (double)k;

@@ -197,7 +197,8 @@ def test_staged_rows_kernel_on_small_shapes():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     shapes = ["3,50,512", "5,300,1024", "9,33,256", "16,130,4096", "16,100,768", "12,257,2304", "17,257,1280", "32,128,2048", "25,40,256",
               "32,128,4096", "20,100,2560", "16,130,8192", "7,300,5120", "16,20000,256", "8,40000,256", "20,5000,2048", "6,70000,256", "24,10000,2048",   # these five: 2 / 4 / 2 / 8 / 4 channel tiles per workgroup
-              "33,96,512", "40,100,1024", "48,50,2048", "49,300,1280", "64,2048,2048", "57,9000,768", "64,33,256"]   # 33 .. 64 rows: three / four row blocks, the waves split 2 / 4 tiles
+              "33,96,512", "40,100,1024", "48,50,2048", "49,300,1280", "64,2048,2048", "57,9000,768", "64,33,256",
+              "40,96,4096", "64,200,3072", "50,5000,2304"]   # four phases: 33 .. 64 rows up to k = 4096   # 33 .. 64 rows: three / four row blocks, the waves split 2 / 4 tiles
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_plan.py"), *shapes],
                          env=dict(os.environ, TVL_ROWS_STAGED="2", CHECK_EXTRA="0,16,32"), capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
