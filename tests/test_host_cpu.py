@@ -197,3 +197,31 @@ def test_inline_asm_load_audit_is_part_of_the_build():
         text = open(os.path.join(csrc, "build", name)).read()
         assert "TOTAL suspicious copies: 0" in text and kernel in text, name
         assert len(re.findall(r"load destinations \d+ regs", text)) >= 4, f"{name}: too few kernel instances audited"
+
+
+def test_planner_model_in_python_has_the_librarys_cost_table():
+    """tools/planner_model.py restates the tile planner's cost model to score rule changes against measured plan timings
+    (profiles/r02_planner_audit.jsonl); its table must be the library's (gemm_mfma.hip: TILE_COSTS), and on the committed audit
+    data the model's picks must stay close to the best pinned plan."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "ternary-vllm_amd", "csrc", "gemm_mfma.hip")).read()
+    body = src[src.index("static const TileCost TILE_COSTS[]"):]
+    body = body[:body.index("};")]
+    kinds = {"KIND_BIG": 2, "KIND_MID": 1, "KIND_SMALL": 0}
+    lib = [(kinds[m.group(1)],) + tuple(float(v) for v in m.group(2).split(","))
+           for m in re.finditer(r"\{(KIND_\w+),([^}]*)\}", body)]
+    py = open(os.path.join(root, "tools", "planner_model.py")).read()
+    tab = py[py.index("TILE_COSTS = ["):]
+    tab = tab[:tab.index("]\n")]
+    names = {"BIG": 2, "MID": 1, "SMALL": 0}
+    mine = [(names[m.group(1)],) + tuple(float(v) for v in m.group(2).split(","))
+            for m in re.finditer(r"\((BIG|MID|SMALL),([^)]*)\)", tab)]
+    assert lib == mine and len(lib) == 5
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "planner_model.py"), os.path.join(root, "profiles", "r02_planner_audit.jsonl")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    regret = float(re.search(r"mean regret ([0-9.]+) %", out.stdout).group(1))
+    assert regret < 1.5, out.stdout
