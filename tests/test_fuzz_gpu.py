@@ -1,6 +1,6 @@
 """Randomised parity sweep of the fused matmul against the CPU oracle (needs an MI355X).
 
-Shapes are drawn around the dispatch boundaries of the kernels (row counts 1 / 4 / 16 / 32, K multiples of 32 / 64 /
+Shapes are drawn around the dispatch boundaries of the kernels (row counts 1 / 4 / 16 / 32 / 48 / 64, K multiples of 32 / 64 /
 256 and odd K, channel counts around tile edges), with random choice of activation dtype, output dtype, bias, fused
 activation, the channel the activation starts at, row strides and over-wide packed rows including code 3.  Inputs are
 on the dyadic grid k/64, so every partial sum is exact in float32 and the result must equal the oracle bit for bit
@@ -15,7 +15,7 @@ from oracle import ternary_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-M_CHOICES = [1, 2, 3, 4, 5, 8, 15, 16, 17, 31, 32, 33, 63, 64, 100, 129, 255, 256, 257, 300, 513]
+M_CHOICES = [1, 2, 3, 4, 5, 8, 15, 16, 17, 31, 32, 33, 48, 49, 63, 64, 100, 129, 255, 256, 257, 300, 513]
 K_CHOICES = [4, 28, 32, 36, 60, 64, 96, 100, 128, 192, 256, 320, 512, 768, 1000, 1024, 1280, 2048, 2080, 4096]
 N_CHOICES = [1, 2, 7, 16, 31, 32, 33, 64, 100, 127, 128, 129, 200, 256, 257, 384, 511, 512, 640, 1000, 2050]
 
