@@ -483,6 +483,9 @@ static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x,
 // n <= 16384): 64 x 2048^2 10.5 -> 8.8, 64 x 6144 x 2048 13.0 -> 9.5, 64 x 14336 x 2048 14.5 -> 12.1, 48 x 14336 x 2048 15.2 -> 10.5,
 // 40 x 6144 x 2048 12.3 -> 8.0, 64 x 1024^2 7.9 -> 5.5 against the 64-row matrix-core tile + reduce / the shared-activation kernel.
 // TVL_ROWS_STAGED=0 turns it off (tuning), 2 lifts the size rules (tests).
+// 3 .. 5 rows on up to 2048 channels with k > 4096: the plain kernel (four waves split k, x from global memory) beats both LDS-staged forms, whose
+// staging of a long k is not repaid by so few rows and workgroups (3 x 2048 x 8192: 8.3 -> 7.4 us, 5 x 2048 x 6144: 8.1 -> 6.8)
+static bool rows_few_long_k(int64_t m, int64_t n, int64_t k) { return m <= 5 && n <= 2048 && k > 4096; }
 static bool rows_use_staged(int64_t m, int64_t n, int64_t k) {
     static const int mode = [] { const char* e = getenv("TVL_ROWS_STAGED"); return e ? atoi(e) : 1; }();   // 2: whatever fits (tests)
     if (m > 64 || k > (m <= 16 ? 8192 : 4096)) return false;   // (17 .. 32 rows in four phases up to k = 8192: built, 12.4 - 13.9 us against 9.0 - 13.1 without)
@@ -497,6 +500,7 @@ static bool rows_use_staged(int64_t m, int64_t n, int64_t k) {
     }
     const double weights = (double)n * (double)k;
     if (mode == 0 || m < 3 || weights < 1.0e6) return false;
+    if (rows_few_long_k(m, n, k)) return false;
     if (k <= 1024 && weights >= 2.0e7) return false;
     const int mr = m <= 16 ? 1 : 2, ct = rows_staged_tiles(m, n, k);
     int64_t per_cu = (int64_t)(160 * 1024) / (int64_t)(rows_staged_lds_bytes(mr, ct, k) + 1024);
@@ -741,6 +745,7 @@ bool gemm_rows_shared_supported(const void* x, int x_dtype, int64_t m, int64_t k
     if (n > INT32_MAX - 512 || k > INT32_MAX) return false;
     if (any_size) return true;
     if (rows_use_staged(m, n, k)) return false;   // x fits in LDS and one round of workgroups covers n: the one-launch kernel above
+    if (rows_few_long_k(m, n, k)) return false;
     // Measured crossovers against the kernels above / the split-K tiles, in weights (n k): e.g. us at 16 rows 15.4 -> 9.4 at
     // 14336 x 2048, 17.1 -> 10.7 at 4096 x 8192, 19.1 -> 12.8 at 8192^2, 39 -> 29 at 16384^2, but 8.5 -> 9.2 at 4096^2; at 48
     // rows 42 -> 21 at 8192^2; at 64 rows the 64-row matrix-core tile keeps 8192^2 (20.5 against 22.5) and loses 16384^2 (60 -> 52).

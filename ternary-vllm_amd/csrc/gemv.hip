@@ -83,15 +83,11 @@ __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__
                                                           float clip, int act, int act_begin, TY* __restrict__ y, int64_t ld_y) {
     __shared__ LutEntry<TX> lut[2][256];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 512; i += 64 * WAVES) lut[i >> 8][i & 255] = make_entry<TX>(i & 255);
-    __syncthreads();
-    const LutEntry<TX>* my_lut = lut[lane & 1];
 
     // KSPLIT: the block's waves share CH channels and take k ranges 2048 * (wave + WAVES * i); otherwise each wave has
     // its own CH channels and the whole k range
     const int wave = threadIdx.x >> 6;
     const int ch0 = KSPLIT ? blockIdx.x * CH : (blockIdx.x * WAVES + wave) * CH;   // wave-uniform
-    if (!KSPLIT && ch0 >= n) return;
     const uint8_t* wrow[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -105,16 +101,26 @@ __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__
         for (int c = 0; c < CH; ++c) acc[r][c] = 0.0f;
 
     const int kstart = (KSPLIT ? 2048 * wave : 0) + 32 * lane, kstride = KSPLIT ? 2048 * WAVES : 2048;
-    for (int k0 = kstart; k0 < k; k0 += kstride) {
-        uint2 wq[CH];
+    uint2 wq[CH];
+    XVec<TX> xv[ROWS];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {   // once-read weight stream: non-temporal
             const nt_u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x2*>(wrow[c] + (k0 - 32 * lane) / 4));
             wq[c] = make_uint2(t[0], t[1]);
         }
-        XVec<TX> xv[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) load_x32<TX>(x + (int64_t)(r < m ? r : 0) * ld_x + k0, xv[r]);
+    };
+    // the first step's loads are in flight while the block fills its tables
+    int k0 = kstart;
+    if (k0 < k) fetch(k0);
+    for (int i = threadIdx.x; i < 512; i += 64 * WAVES) lut[i >> 8][i & 255] = make_entry<TX>(i & 255);
+    __syncthreads();
+    const LutEntry<TX>* my_lut = lut[lane & 1];
+    if (!KSPLIT && ch0 >= n) return;
+
+    while (k0 < k) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             LutEntry<TX> e[8];   // 32 weights of channel c
@@ -148,6 +154,8 @@ __global__ void __launch_bounds__(64 * WAVES) gemv_kernel(const TX* __restrict__
                 acc[r][c] = a0 + a1;
             }
         }
+        k0 += kstride;
+        if (k0 < k) fetch(k0);
     }
 
     const float cl = fabsf(clip);
@@ -222,9 +230,13 @@ static void launch_gemv_rows(const TX* x, int64_t m, int64_t k, int64_t ld_x, co
 template <typename TX, typename TY>
 static int launch_gemv_xy(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw, const float* scale,
                           const float* bias, float clip, int act, int act_begin, TY* y, int64_t ld_y, hipStream_t st) {
-    // few channels: 2 per wave so that the layer still makes >= 2 waves per SIMD; many channels: 8 per wave (activations
-    // reused), and with a long k the block's 4 waves split it (4x the waves and the bytes in flight)
-    if (n < 16384) launch_gemv_rows<TX, TY, 2, 4, false>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, st);
+    // few channels: 2 per wave so that the layer still makes >= 2 waves per SIMD, and with k >= 4096 on layers of up to 6144 channels
+    // the block's 4 waves split k over 2 or 4 shared channels (1 x 2048 x 8192: 5.0 -> 3.8 us, 2 x 2048 x 8192: 6.2 -> 4.7, 1 x 4096 x
+    // 14336: 7.9 -> 7.1); many channels: 8 per wave (activations reused), and with a long k the waves split it as well
+    if (n <= 6144 && k >= 4096) {
+        if (n <= 2048 && m == 1) launch_gemv_rows<TX, TY, 2, 4, true>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, st);
+        else launch_gemv_rows<TX, TY, 4, 4, true>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, st);
+    } else if (n < 16384) launch_gemv_rows<TX, TY, 2, 4, false>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, st);
     else if (k >= 8192) launch_gemv_rows<TX, TY, 8, 4, true>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, st);
     else launch_gemv_rows<TX, TY, 8, 1, false>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, ld_y, st);
     TVL_LAUNCH_CHECK();

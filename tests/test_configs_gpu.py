@@ -203,3 +203,20 @@ def test_staged_rows_kernel_on_small_shapes():
                          env=dict(os.environ, TVL_ROWS_STAGED="2", CHECK_EXTRA="0,16,32"), capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert out.stdout.count(": ok") == 6 * len(shapes)
+
+
+def test_table_lookup_kernel_geometries_on_one_to_four_rows():
+    """The one-to-four-row table-lookup kernel in each launch geometry: waves that own channels (short k, many channels), and
+    blocks whose four waves split k over two (one row, up to 2048 channels) or four shared channels (k >= 4096, up to 6144
+    channels), with ragged channel counts and k that ends inside a wave's range; a child process switches the kernel on
+    wherever it can run (TVL_GEMV=2); every dtype pair against the CPU oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = ["1,2048,8192", "1,1001,4096", "2,2050,4128", "4,5000,4096", "3,6144,8192", "1,6145,4096", "1,300,12288", "2,130,6176",
+              "4,2048,2048", "1,17000,4096", "2,16390,8192"]
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_plan.py"), *shapes],
+                         env=dict(os.environ, TVL_GEMV="2", CHECK_EXTRA="0,8,16"), capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert out.stdout.count(": ok") == 6 * len(shapes)
