@@ -2,7 +2,7 @@
 // shader-clock (s_memtime) and 100 MHz (s_memrealtime) stamps at entry, around the k loop and after the epilogue, runs back-to-back
 // launches on random data for ~2 s and prints, as medians over workgroups of the LAST launch: the clock held over the k loop,
 // cycles and microseconds of prologue / loop / epilogue, cycles per 64-deep k step.
-//   usage: gemm_clock [form=0|1|2] [M N K [splits]]   (0: the shipped 256 x 256 tile, 1: four waves x 64 channels, 2: 128 x 128 split-K)
+//   usage: gemm_clock [form=0|1|2] [M N K [splits [lds_tiles]]]   (0: the shipped 256 x 256 tile, 1: four waves x 64 channels, 2: 128 x 128 split-K)
 #define TVL_CLOCK_PROBE 1
 #include "../../ternary-vllm_amd/csrc/gemm_mfma_kernels.h"
 
@@ -18,8 +18,8 @@ using namespace tvl;
 static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
 // the mid-size path's split-K form: 128 x 128 tiles of four waves, `splits` k ranges per tile, raw float32 partial sums to slabs
+template <int NB>
 static void run_mid_split(int m, int n, int k, int splits, const f16* x, const uint8_t* pw, const float* sc, const float* bi, float* slab) {
-    constexpr int NB = 4;
     auto kern = gemm_mfma16_kernel<f16, float, false, TVL_ACT_NONE, 1, false, NB, 128, 4, true, 3>;
     const size_t lds = (size_t)NB * 128 * ROW_BYTES;
     CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -45,7 +45,7 @@ static void run_mid_split(int m, int n, int k, int splits, const f16* x, const u
         all_us.push_back((r[3] - r[0]) * 0.01);
         r_first = std::min(r_first, r[0]); r_last = std::max(r_last, r[3]);
     }
-    printf("128 x 128 tiles, %d tiles x %d k ranges of %d steps: %.2f us per launch (event pair)\n", nblk, splits, per, ms / 5000 * 1e3);
+    printf("128 x 128 tiles, %d LDS tiles, %d tiles x %d k ranges of %d steps: %.2f us per launch (event pair)\n", NB, nblk, splits, per, ms / 5000 * 1e3);
     printf("  clock over the k loop %.3f GHz   prologue %.2f us   k loop %.2f us (%.0f cyc per step)   epilogue (slab stores) %.2f us   workgroup lifetime %.2f us\n",
            med(ghz), med(pro_us), med(loop_us), med(loopc) / per, med(epi_us), med(all_us));
     printf("  first workgroup entry to last workgroup exit (k range 0 only): %.2f us\n", (r_last - r_first) * 0.01);
@@ -113,7 +113,11 @@ int main(int argc, char** argv) {
     if (wide == 2) {   // gemm_clock 2 M N K splits
         const int splits = argc > 5 ? atoi(argv[5]) : 4;
         float* slab; CHECK(hipMalloc(&slab, (size_t)splits * m * n * 4));
-        run_mid_split(m, n, k, splits, x, pw, sc, bi, slab);
+        const int nb = argc > 6 ? atoi(argv[6]) : 4;   // LDS tiles: a tile is requested nb - 2 steps before its use
+        if (nb == 6) run_mid_split<6>(m, n, k, splits, x, pw, sc, bi, slab);
+        else if (nb == 5) run_mid_split<5>(m, n, k, splits, x, pw, sc, bi, slab);
+        else if (nb == 3) run_mid_split<3>(m, n, k, splits, x, pw, sc, bi, slab);
+        else run_mid_split<4>(m, n, k, splits, x, pw, sc, bi, slab);
         return 0;
     }
     if (wide) run<4, 64, 1>(m, n, k, x, pw, sc, bi, y);

@@ -10,7 +10,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("TVL_PKG_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # TVL_PKG_ROOT: a copy of the package with another build of the library (A/B runs)
 import ternary_vllm_amd as tv  # noqa: E402
 
 ops = tv.custom_ops_mod
