@@ -174,7 +174,7 @@ static const TileCost TILE_COSTS[] = {
     {KIND_MID, 128, 256, 1, 7.0, 0.62, 0.84, 0.84},     // 8 waves, 64 KiB LDS
     {KIND_MID, 128, 128, 2, 6.0, 0.42, 0.50, 0.49},     // 4 waves, 64 KiB LDS
     {KIND_MID, 64, 128, 4, 5.0, 0.28, 0.36, 0.30},      // 4 waves, 32 KiB LDS
-    {KIND_SMALL, 32, 128, 3, 4.0, 0.21, 0.21, 0.21},
+    {KIND_SMALL, 32, 128, 3, 3.5, 0.32, 0.32, 0.21},
 };
 
 // TVL_FORCE_PLAN="kind:bm:bn:splits" pins the choice (tuning and tests: every tile can be timed on every shape); read once.
@@ -205,7 +205,9 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t workspace_byte
     double best_t = 1e30;
     for (const TileCost& tc : TILE_COSTS) {
         if (tc.bm > 32 && m <= tc.bm / 2) continue;   // more than half of the tile's rows would be padding
-        if (tc.bm == 32 && m > 48) continue;          // two row tiles per decoded weight: only where taller tiles would be mostly padding
+        // the 32-row tile (two row tiles per decoded weight): where taller tiles would be mostly padding, and up to 160 rows on layers so small
+        // that 64-row tiles with 8 k ranges still leave compute units idle (128 x 1152 x 1152: 9.7 -> 8.0 us)
+        if (tc.bm == 32 && m > 48 && !(m <= 160 && ceil_div(m, 64) * ceil_div(n, 128) * 8 < cus)) continue;
         const int64_t tiles = ceil_div(m, tc.bm) * ceil_div(n, tc.bn);
         for (int64_t s = 1; s <= 64; ++s) {
             if (s > 1 && (s > max_by_ws || steps / s < 2 || tc.kind == KIND_BIG)) break;

@@ -493,9 +493,9 @@ static bool rows_use_staged(int64_t m, int64_t n, int64_t k) {
     if (mode == 2) return true;
     if (m > 32) {   // one round of workgroups (one per CU: 133 KiB of LDS) on two or four tiles each
         if (mode == 0) return false;
-        // four phases (k > 2048) pay on wide layers only: 40 x 8192 x 4096 15.0 -> 13.0, 64 x 14336 x 4096 22.2 -> 19.0, but 40 x 2048 x 4096 10.7 -> 12.1,
+        // four phases (k > 2048) pay on wide layers only: 40 x 8192 x 4096 15.0 -> 13.0, 64 x 14336 x 4096 22.2 -> 19.0, 40 x 3072^2 10.9 -> 10.2, but 40 x 2048 x 4096 10.7 -> 12.1,
         // 64 x 8192 x 4096 13.6 -> 15.9
-        if (k > 2048 && n < (m <= 48 ? 4096 : 10000)) return false;
+        if (k > 2048 && n < (m <= 48 ? 3072 : 10000)) return false;
         return (double)n * (double)k >= 1.0e6 && ceil_div(n, 64) <= (int64_t)device_cu_count();
     }
     const double weights = (double)n * (double)k;

@@ -16,7 +16,7 @@ TILE_COSTS = [
     (MID, 128, 256, 1, 7.0, 0.62, 0.84, 0.84),
     (MID, 128, 128, 2, 6.0, 0.42, 0.50, 0.49),
     (MID, 64, 128, 4, 5.0, 0.28, 0.36, 0.30),
-    (SMALL, 32, 128, 3, 4.0, 0.21, 0.21, 0.21),
+    (SMALL, 32, 128, 3, 3.5, 0.32, 0.32, 0.21),
 ]
 
 
@@ -30,7 +30,7 @@ def plan(m, n, k):
     for (kind, bm, bn, occ, fixed, light, full, shared) in TILE_COSTS:
         if bm > 32 and m <= bm // 2:
             continue
-        if bm == 32 and m > 48:
+        if bm == 32 and m > 48 and not (m <= 160 and cdiv(m, 64) * cdiv(n, 128) * 8 < CUS):
             continue
         tiles = cdiv(m, bm) * cdiv(n, bn)
         for s in range(1, 65):
