@@ -1,4 +1,4 @@
-# usage: bash tools/plans_sweep.sh <out.jsonl> "<shapes>" "<plans>" "<variants>"
+# usage: bash tools/plans_sweep.sh <out.jsonl> "<shapes>" "<plans>" "<variants>" (the 4th argument sets TVL_MID_VARIANT, which only experimental builds of the mid-size kernel read; default 1)
 set -e
 OUT=$1; S=$2; PLANS=$3; VARS=${4:-1}
 mkdir -p $(dirname $OUT)

@@ -1,4 +1,4 @@
-# usage: bash tools/pmc_shape.sh <tag> <plan|auto> <variant> M N K  -> gpurun_out/r2/pmc_<tag>.txt : counters of the matmul kernel(s) for one shape
+# usage: bash tools/pmc_shape.sh <tag> <plan|auto> <variant> M N K  -> gpurun_out/r2/pmc_<tag>.txt : counters of the matmul kernel(s) for one shape  (<variant> sets TVL_MID_VARIANT, read by experimental builds only: pass 0)
 set -e
 TAG=$1; PLAN=$2; VAR=$3; M=$4; N=$5; K=$6
 R=${GRAFT_REPO_ROOT:-/root/repo}
