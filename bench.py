@@ -19,7 +19,9 @@ Rank 0 prints ONE JSON line.  `value` = total ternary-GEMM operations (2 M N K p
 per second in GOPS.  `roofline` prices the GEMM kernel against the dense f16 matrix-core peak (this
 shape is compute-bound, 1 927 op/byte); `hbm` gives the same launch as a fraction of HBM bandwidth
 (the metric's second half) plus the HBM-bound kernels of the path (quantize+pack, skinny-M GEMM).
-`cpu_baseline` times a CPU restatement of the reference op on the host's cores (bounded sample).
+`cpu_baseline` times a CPU restatement of the reference op on the host's cores (bounded sample); `parity` holds the
+errors of the GPU path on this workload against the C restatement / float64 (outside the timed region); `configs` the
+ViT-Base/16 (batch 128) and batch-256 decode shapes of the other benchmark configurations.
 """
 import argparse
 import ctypes
@@ -36,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
+HBM_ACHIEVABLE_GBS = 6300.0  # what a plain 16-byte-per-lane copy reaches on this part (79 % of the spec figure)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 matrix-core peak
 
 
@@ -157,6 +160,45 @@ def cpu_baseline(m_full, n, k, seed, budget_s=12.0):
         res[:, i] = mm_[:, r > 0].sum(dim=1) - mm_[:, r < 0].sum(dim=1)
     out["ternary_mm_1024_loop_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
     return out
+
+
+def parity_block(ops, dev, pw, scale, bias, x_randn, M, N, K, threads):
+    """Errors of the GPU path on the benchmark's own workload, checked with the C restatement (oracle/ternary_oracle.c) outside
+    every timed region: (1) dyadic-grid activations (every partial sum exact in float32, so any correct kernel gives the oracle's
+    bits): the full M x N product on the GPU, every 8th row compared; (2) the N(0,1) activations of the timed runs: 48 rows
+    against a float64 evaluation, next to the error of a float32 CPU evaluation of the same rows."""
+    from __graft_entry__ import ORACLE_SO
+    lib = ctypes.CDLL(ORACLE_SO)
+    fn = lib.tvo_ternary_matmul_dense_f32
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                   ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_int]
+    pw_h = np.ascontiguousarray(pw.cpu().numpy())
+    sc_h, bi_h = np.ascontiguousarray(scale.cpu().numpy()), np.ascontiguousarray(bias.cpu().numpy())
+
+    def cpu_f32(x_rows):
+        x_rows = np.ascontiguousarray(x_rows, dtype=np.float32)
+        y = np.empty((x_rows.shape[0], N), np.float32)
+        rc = fn(x_rows.ctypes.data, x_rows.shape[0], K, pw_h.ctypes.data, pw_h.shape[1], N, sc_h.ctypes.data, bi_h.ctypes.data, 100.0, y.ctypes.data, threads)
+        assert rc == 0
+        return y
+
+    g = torch.Generator().manual_seed(4321)
+    xg = (torch.randint(-64, 65, (M, K), generator=g).float() / 64.0).half()
+    yg = ops.ternary_matmul(xg.to(dev), pw, scale, bias, 100.0, out_dtype=torch.float32).cpu().numpy()
+    rows = np.arange(0, M, 8)
+    grid_err = float(np.abs(yg[rows] - cpu_f32(xg[rows].float().numpy())).max())
+    # N(0,1): float64 evaluation of 48 rows spread over the batch
+    rr = np.linspace(0, M - 1, 48).astype(np.int64)
+    yr = ops.ternary_matmul(x_randn, pw, scale, bias, 100.0, out_dtype=torch.float32)[torch.from_numpy(rr).to(dev)].cpu().numpy()
+    xr = x_randn[torch.from_numpy(rr).to(dev)].float().cpu().numpy()
+    codes = pw_h[:, :K // 4]
+    w64 = np.stack([((codes >> (2 * i)) & 3).astype(np.float64) - 1.0 for i in range(4)], axis=-1).reshape(N, K)
+    y64 = np.clip((xr.astype(np.float64) @ w64.T) * sc_h.astype(np.float64) + bi_h.astype(np.float64), -100.0, 100.0)
+    return {"grid_max_abs": grid_err, "grid_rows_compared": int(rows.size), "grid_note": "x = k/64: exact partial sums, expected 0",
+            "randn_max_abs_vs_f64": float(np.abs(yr - y64).max()), "cpu_f32_max_abs_vs_f64": float(np.abs(cpu_f32(xr) - y64).max()),
+            "randn_rows_compared": 48, "randn_output_rms": float(np.sqrt(np.mean(y64 ** 2))),
+            "checker": "oracle/ternary_oracle.c tvo_ternary_matmul_dense_f32 (float32) and numpy float64; f16 activations, float32 GPU output"}
 
 
 def launch_ranks(n):
@@ -360,15 +402,16 @@ def main():
         traffic, traffic_note = None, None
         try:   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes: valid for the profiled binary and shape only
             import hashlib
-            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+            tpath = next(p_ for p_ in (os.path.join(ROOT, "profiles", f"r0{r_}_traffic.json") for r_ in (3, 2)) if os.path.exists(p_))
+            with open(tpath) as f:
                 tj = json.load(f)
             with open(ops.LIBRARY_PATH, "rb") as f:
                 same_binary = hashlib.sha256(f.read()).hexdigest() == tj.get("library_sha256")
             if (M, N, K) == (4096, 4096, 4096) and same_binary:
                 traffic = tj["gemm_4096x4096x4096_f16"]["traffic_bytes"]
             elif (M, N, K) == (4096, 4096, 4096):
-                traffic_note = "profiles/r02_traffic.json was collected with another build of the library: not reported"
-        except (OSError, KeyError, ValueError):
+                traffic_note = f"profiles/{os.path.basename(tpath)} was collected with another build of the library: not reported"
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         roofline = {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved_tf / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
@@ -389,7 +432,8 @@ def main():
             hbm["pack_kernel"] = {"kernel": "tvl::quantize_pack_fast_kernel<float, ternary>", "shape": [N, K],
                                   "algorithmic_bytes": pack_bytes, "avg_launch_ms": round(p_avg, 4),
                                   "GBps": round(pack_bytes / (p_avg * 1e-3) / 1e9, 1),
-                                  "frac_of_hbm_peak": round(pack_bytes / (p_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                  "frac_of_hbm_peak": round(pack_bytes / (p_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "frac_of_achievable_6300": round(pack_bytes / (p_avg * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, 4)}
             del wl, pws
             # the arena case: every quantized layer of a moondream-sized checkpoint (22 blocks x Wqkv, out_proj, fc1, fc2) in one
             # batched call - the form the conversion path really runs (utils/conversion.py:126-137, one pack per Dense)
@@ -400,7 +444,8 @@ def main():
             a_bytes = sum(n_ * k_ * 4 + n_ * k_ // 4 for (n_, k_) in shapes)
             hbm["pack_arena"] = {"kernel": "tvl::quantize_pack_batch_kernel<float, ternary> (up to 64 matrices per launch)", "layers": len(shapes), "timing": a_how,
                                  "algorithmic_bytes": a_bytes, "avg_call_ms": round(a_avg, 4), "GBps": round(a_bytes / (a_avg * 1e-3) / 1e9, 1),
-                                 "frac_of_hbm_peak": round(a_bytes / (a_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                 "frac_of_hbm_peak": round(a_bytes / (a_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "frac_of_achievable_6300": round(a_bytes / (a_avg * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, 4)}
             del lat, dst
             # one large matrix (1 GiB of latent weights): the kernel's rate without launch ramps and tails
             big_w = torch.rand(16384, 16384, device=dev) * 2 - 1
@@ -409,7 +454,8 @@ def main():
             b_bytes = 16384 * 16384 * 4 + 16384 * 4096
             hbm["pack_16384"] = {"kernel": "tvl::quantize_pack_fast_kernel<float, ternary>", "shape": [16384, 16384], "timing": b_how,
                                  "algorithmic_bytes": b_bytes, "avg_launch_ms": round(b_avg, 4), "GBps": round(b_bytes / (b_avg * 1e-3) / 1e9, 1),
-                                 "frac_of_hbm_peak": round(b_bytes / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                 "frac_of_hbm_peak": round(b_bytes / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "frac_of_achievable_6300": round(b_bytes / (b_avg * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, 4)}
             del big_w, big_o
             # ---- HBM-bound form of the matmul: few activation rows (decode / small batches), weights streamed once from HBM.
             # 16384 x 16384 (64 MiB packed, 10 rotating copies) is large enough to leave the launch-latency regime.
@@ -450,6 +496,33 @@ def main():
                 t_avg, _, how = time_graph(lambda i: ops.ternary_mm(mm_, tm_), 20, 5)
                 cfg1[str(size)] = {"avg_call_ms": round(t_avg, 5), "GOPS": round(2.0 * size ** 3 / (t_avg * 1e-3) / 1e9, 1), "timing": how}
             extra["config1_ternary_mm"] = cfg1
+
+            # ---- BASELINE configurations 3 and 4 under the same clock: the ViT-Base/16 Dense stack at batch 128 (M = 128 x 197 tokens) and
+            # the packed matmuls of one batch-256 decode step of the Phi-shaped text model (Wqkv | fc1 as one product, GELU from 6144)
+            cfg_rows = []
+            for (mm, nn, kk, tag, act, act_begin) in (
+                    (128 * 197, 2304, 768, "config3 vit_b16 qkv", None, 0), (128 * 197, 768, 768, "config3 vit_b16 attn_out", None, 0),
+                    (128 * 197, 3072, 768, "config3 vit_b16 fc1+gelu", "gelu_tanh", 0), (128 * 197, 768, 3072, "config3 vit_b16 fc2", None, 0),
+                    (256, 14336, 2048, "config4 decode_b256 Wqkv|fc1 (gelu from 6144)", "gelu_tanh", 6144),
+                    (256, 2048, 2048, "config4 decode_b256 out_proj", None, 0), (256, 2048, 8192, "config4 decode_b256 fc2", None, 0)):
+                nb = max(2, min(16, int(600e6 // max(1, nn * kk // 4 + mm * kk * 2))))   # operands rotate through > 256 MiB where they are small
+                pwl = [torch.randint(0, 171, (nn, kk // 4), dtype=torch.uint8, device=dev) for _ in range(nb)]
+                xl = [torch.randn(mm, kk, device=dev).half() for _ in range(nb)]
+                yl = [torch.empty((mm, nn), dtype=torch.float16, device=dev) for _ in range(nb)]
+                sc_, bi_ = torch.rand(nn, device=dev) + 0.5, torch.randn(nn, device=dev)
+                call = lambda i: ops.ternary_matmul(xl[i % nb], pwl[i % nb], sc_, bi_, 100.0, activation=act, act_begin=act_begin, out=yl[i % nb])  # noqa: E731
+                if 2.0 * mm * nn * kk < 2e10:
+                    a_ms, _, how = time_graph(call, 2 * nb, nb)
+                else:
+                    a_ms, _ = time_launches(call, 60, 100, rounds=3)
+                    how = "event pair around 60 launches"
+                by_ = gemm_bytes(mm, nn, kk, 2)
+                cfg_rows.append({"name": tag, "shape": [mm, nn, kk], "us": round(a_ms * 1e3, 2),
+                                 "frac_mfma": round(2.0 * mm * nn * kk / (a_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                                 "frac_hbm": round(by_ / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel": ops.matmul_route(torch.float16, mm, nn, kk),
+                                 "timing": how})
+                del pwl, xl, yl
+            extra["configs"] = cfg_rows
 
             # ---- the same workload with float32 activations (the reference layer's dtype): three exact bf16 planes on
             # the matrix cores, float32 output
@@ -496,6 +569,10 @@ def main():
         }
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(M, N, K, seed)
+            try:   # the checker's verdict on this very workload, beside the CPU baseline it shares the host leg with
+                result["parity"] = parity_block(ops, dev, pw, scale, bias, xs[0], M, N, K, result["cpu_baseline"]["cores"])
+            except Exception as e:  # noqa: BLE001
+                result["parity"] = {"error": f"{type(e).__name__}: {e}"}
         else:
             result["cpu_baseline"] = None
         result.update(extra)

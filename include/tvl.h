@@ -20,6 +20,22 @@
  *     k = 4j..4j+3 of output channel n, weight i in bits [2i+1:2i], code = value + 1
  *     (-1 -> 0, 0 -> 1, +1 -> 2; code 3 decodes to +2 exactly like the reference's
  *     `((b >> 2i) & 3) - 1`).  impl/tf/moondream/ternary.py:374-398 (pack), :507-520 (decode).
+ *
+ * Hardware assumptions
+ *   - built for gfx950 (MI355X) only.  The tile order of the matrix-core kernels assumes 8 XCDs (workgroups with equal
+ *     blockIdx % 8 share an L2): on a part with another count results stay correct, only the L2 reuse of the order is lost.
+ *     The compute-unit count is read from the device, the kernel-choice cost tables are calibrated on MI355X.
+ *
+ * Tuning switches (environment variables, each read ONCE per process at the first matmul; results never depend on them,
+ * only which kernel computes them; unset = the library's own choice; meant for tuning runs and the test suite, leave them
+ * unset in production)
+ *   TVL_FORCE_PLAN=kind:bm:bn:splits   pin the matrix-core tile and k split (kind 0 = 32x32x16 small tiles, 1 = 128-row tiles,
+ *                                      2 = the 256 x 256 tile; splits -1 with 1:128:256 = two workgroups per compute unit)
+ *   TVL_TAIL_SPLIT=0                   never split a ragged last round of big tiles into a second launch
+ *   TVL_MID_PERSIST=0|1                pin the persistent form of the 128 x 256 tile off / on
+ *   TVL_ROWS_STAGED=0|2                few-row kernel with x staged once in LDS: off / wherever it fits
+ *   TVL_ROWS_SHARED=<splits>|-1        few-row kernel for larger layers: pin its k split / off;  TVL_ROWS_SHARED_ANY=1 lifts its size rules
+ *   TVL_GEMV=0|2                       one- and two-row kernel: off / wherever it can run
  */
 #ifndef TVL_H_
 #define TVL_H_
@@ -132,12 +148,29 @@ int tvl_ternary_matmul_act_from(const void* x, int x_dtype, int64_t m, int64_t k
                                 int y_dtype, int64_t ld_y, void* workspace, size_t workspace_bytes, void* stream);
 size_t tvl_ternary_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k);
 size_t tvl_ternary_matmul_workspace_bytes_for(int x_dtype, int64_t m, int64_t n, int64_t k);
+/* tvl_ternary_matmul_act_from followed by  y = (y + add1) + add2  in y's type, as ONE call: the closing line of the
+ * reference's decoder block, `hidden_states = attn_outputs + feed_forward_hidden_states + residual`
+ * (impl/tf/moondream/layers.py:345-347), rides on fc2's product with add1 = out_proj's output and add2 = the block's input.
+ * add1 / add2: [m, ld_add* >= n] of y's type (ld 0 = dense), not overlapping y; add2, or both, may be NULL.  Every sum is rounded to y's type, so
+ * the result has the bits of the unfused sequence (product, then two element-wise additions) - for float32 outputs the
+ * reference's own value.  Where the chosen kernels end in the split-K reduction the addends ride in its epilogue; otherwise the
+ * library appends one element-wise launch (still one call, no extra pass through the host). */
+int tvl_ternary_matmul_residual(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n,
+                                int64_t ld_pw, const float* scale, const float* bias, float clip, int act,
+                                int64_t act_begin_channel, const void* add1, int64_t ld_add1, const void* add2,
+                                int64_t ld_add2, void* y, int y_dtype, int64_t ld_y, void* workspace, size_t workspace_bytes,
+                                void* stream);
+/* Host-side description of the kernels tvl_ternary_matmul would launch for dense, aligned operands of this shape with a
+ * workspace of `workspace_bytes` (names of the kernel templates in ternary-vllm_amd/csrc; no counterpart in the reference,
+ * which never says which kernel ran).  For benchmark records and tests; `out` is a host buffer. */
+int tvl_ternary_matmul_route(int x_dtype, int64_t m, int64_t n, int64_t k, size_t workspace_bytes, char* out, size_t out_len);
 
 /* tvl_ternary_matmul_act_from for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The scratch memory the other
  * entry points take as `workspace` is a buffer built into the library instead: TVL_NOALLOC_SCRATCH_BYTES of device
- * memory per GPU, held until the process ends.  The call allocates and frees nothing (its first use on a GPU looks the
- * buffer's address up once).  Same results, bit for bit, as tvl_ternary_matmul_act_from given a workspace of
+ * memory per GPU, held until the process ends.  The call allocates and frees nothing.  Every call looks the buffer's
+ * address up; the FIRST call on a GPU does so through hipGetSymbolAddress, a runtime call that is not a stream operation:
+ * make one call (m = 0 is enough, it launches nothing) on each GPU before starting a stream capture there.  Same results, bit for bit, as tvl_ternary_matmul_act_from given a workspace of
  * tvl_ternary_matmul_workspace_bytes_for(x_dtype, m, n, k) bytes; a shape that needs more than the built-in buffer is
  * rejected with TVL_ERR_INVALID and nothing is launched (tvl_noalloc_scratch_bytes() returns the limit).  The device the
  * pointers live on must be current.  All calls on one GPU share that GPU's buffer: calls that overlap in time on one GPU

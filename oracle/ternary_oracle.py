@@ -226,6 +226,34 @@ def ternary_matmul(x, pw, scale, bias, clip_val, k=None, act=ACT_NONE, acc_dtype
     return y.reshape(x.shape[:-1] + (w.shape[0],)).astype(out_dtype)
 
 
+def round_to(a, dtype_name):
+    """float32 values rounded to nearest-even in "f32" / "f16" / "bf16" and returned as float32 (numpy has no bfloat16)."""
+    a = np.asarray(a, dtype=np.float32)
+    if dtype_name == "f32":
+        return a
+    if dtype_name == "f16":
+        return a.astype(np.float16).astype(np.float32)
+    if dtype_name == "bf16":
+        bits = a.view(np.uint32).astype(np.uint64)
+        rounded = ((bits + 0x7FFF + ((bits >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+        out = rounded.view(np.float32).copy()
+        nan = np.isnan(a)
+        out[nan] = np.nan
+        return out
+    raise ValueError(f"Unknown dtype name: {dtype_name}")
+
+
+def ternary_matmul_residual(x, pw, scale, bias, clip_val, add1, add2=None, out="f32", **kw):
+    """The fused op followed by the decoder block's closing sum, ``attn_outputs + feed_forward_hidden_states + residual``
+    (``impl/tf/moondream/layers.py:345-347``), as element-wise additions in the output type: ``(y + add1) + add2`` with the
+    product and every sum rounded to ``out`` ("f32": the reference's own float32 arithmetic).  ``kw``: as ``ternary_matmul``."""
+    y = round_to(ternary_matmul(x, pw, scale, bias, clip_val, **kw), out)
+    y = round_to(y + np.asarray(add1, dtype=np.float32).reshape(y.shape), out)
+    if add2 is not None:
+        y = round_to(y + np.asarray(add2, dtype=np.float32).reshape(y.shape), out)
+    return y
+
+
 def scaled_linear_forward(x, weights, scale, bias, maxval=100.0, quantization="ternary", acc_dtype=np.float64):
     """Dense forward of the torch layers: quantize the latent weights on every
     call, ``F.linear``, ``*= scale``, ``+= bias``, clip.

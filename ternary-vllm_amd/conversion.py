@@ -76,6 +76,8 @@ def to_packed_inference(model: nn.Module, variant: str = "matmul", gelu_names: I
 # ---------------------------------------------------------------------------------------------------
 
 ROW_ALIGN = 16  # bytes: keeps every layer's rows 16-byte aligned inside the arena
+PACK_FLUSH_LAYERS = 64        # layers per batched pack call (one launch takes up to 64 matrix descriptors)
+PACK_FLUSH_BYTES = 2 << 30    # ... or this many bytes of latent weights waiting on the device, whichever comes first
 
 
 def _natural_key(name: str):
@@ -97,6 +99,36 @@ class ArenaEntry:
     quantization: str
 
 
+def checkpoint_layer_selection(keys, start_skip: int = 1, last_skip: int = 0, n_blocks: Optional[int] = None, select=None):
+    """Which quantized layers of a checkpoint are packed: ``(selected prefixes, skipped prefixes)``, both in natural order.
+    A quantized layer is every prefix with ``<prefix>.weights`` and ``<prefix>.scale`` among ``keys``.  The rule is
+    ``quantize_moondream``'s (``binary/utils.py:14-21``) evaluated where the reference evaluates it - on the name of the
+    module whose children ``linear_to_quantized`` converts (``binary/modules.py:191``), i.e. the layer's parent."""
+    import re
+
+    keys = set(keys)
+    if n_blocks is None:
+        blocks = [int(mo.group(1)) for key in keys for mo in [re.search(r"transformer\.h\.(\d+)\.", key)] if mo]
+        n_blocks = max(blocks) + 1 if blocks else 0
+    from .utils import layers_to_skip
+    skip = layers_to_skip(n_blocks, start_skip, last_skip)
+
+    def parent_rule(prefix):
+        parent = prefix.rsplit(".", 1)[0] if "." in prefix else ""
+        return "lm_head" not in parent and not any(s_ in parent for s_ in skip)
+
+    rule = select if select is not None else parent_rule
+    chosen, skipped = [], []
+    for key in sorted(keys, key=_natural_key):
+        if not key.endswith(".weights"):
+            continue
+        prefix = key[: -len(".weights")]
+        if prefix + ".scale" not in keys:
+            continue
+        (chosen if rule(prefix) else skipped).append(prefix)
+    return chosen, skipped
+
+
 class PackedArena:
     """All packed layers of a model in one device buffer.  ``layer(name)`` returns views
     ``(pw [N, ld] uint8, scale [N], bias [N] | None, maxval)`` ready for ``ternary_matmul``."""
@@ -111,7 +143,9 @@ class PackedArena:
     @torch.no_grad()
     def _build(cls, specs, fetch, device) -> "PackedArena":
         """``specs``: list of (name, n, k, maxval, has_bias, quantization); ``fetch(name)`` -> (latent weights [n,k],
-        scale [n], bias [n] | None), called once per layer while the arena is filled (one layer resident at a time)."""
+        scale [n], bias [n] | None), called once per layer while the arena is filled.  Latent weights wait on the device for the
+        batched pack call, which runs every ``PACK_FLUSH_LAYERS`` layers (or ``PACK_FLUSH_BYTES`` of latent weights): the peak is
+        the arena plus one such batch, not the whole checkpoint."""
         entries, off, voff = [], 0, 0
         for name, n, k, maxval, has_bias, quant in specs:
             ld = -(-ops.packed_row_bytes(k) // ROW_ALIGN) * ROW_ALIGN
@@ -121,7 +155,16 @@ class PackedArena:
         packed = torch.full((off,), 0x55, dtype=torch.uint8, device=device)  # pad bytes = four zeros
         scales = torch.empty((voff,), dtype=torch.float32, device=device)
         biases = torch.zeros((voff,), dtype=torch.float32, device=device)
-        pending = {}   # quantization -> (latent weights, arena views): packed together, one launch per 64 layers
+        pending = {}   # (quantization, dtype) -> (latent weights, arena views): packed together, one launch per batch
+        held_layers = held_bytes = 0
+
+        def flush():
+            nonlocal held_layers, held_bytes
+            for (quant, _), (ws, views) in pending.items():
+                ops.ternarize_pack_batch(ws, 0.5, quant, outs=views)
+            pending.clear()   # drops the device copies of the latent weights
+            held_layers = held_bytes = 0
+
         for e in entries:
             w, scale, bias = fetch(e.name)
             if tuple(w.shape) != (e.n, e.k) or scale.numel() != e.n or (bias is not None and bias.numel() != e.n):
@@ -130,11 +173,14 @@ class PackedArena:
             ws, views = pending.setdefault((e.quantization, w.dtype), ([], []))
             ws.append(w.to(device))
             views.append(view)
+            held_layers += 1
+            held_bytes += w.numel() * w.element_size()
             scales[e.vec_offset:e.vec_offset + e.n] = scale.to(device, torch.float32).reshape(-1)
             if bias is not None:
                 biases[e.vec_offset:e.vec_offset + e.n] = bias.to(device, torch.float32).reshape(-1)
-        for (quant, _), (ws, views) in pending.items():
-            ops.ternarize_pack_batch(ws, 0.5, quant, outs=views)
+            if held_layers >= PACK_FLUSH_LAYERS or held_bytes >= PACK_FLUSH_BYTES:
+                flush()
+        flush()
         return cls(packed, scales, biases, entries)
 
     @classmethod
@@ -175,37 +221,29 @@ class PackedArena:
 
     @classmethod
     def from_safetensors(cls, path: str, device, start_skip: int = 1, last_skip: int = 0, quantization: str = "ternary",
-                         maxval: float = 100.0, select=None) -> "PackedArena":
+                         maxval: float = 100.0, select=None, n_blocks: Optional[int] = None) -> "PackedArena":
         """Convert a checkpoint written by the reference's training script (``train.py:336-338``) straight from a local
         ``.safetensors`` file: the counterpart of ``convert.py:70-79`` (quantize the selected layers, then fill their
         parameters from the file) followed by the pack call of ``utils/conversion.py:61-77``.
 
         A quantized layer is every prefix with ``<prefix>.weights`` (latent, [N,K]) and ``<prefix>.scale`` ([N]);
         ``<prefix>.bias`` is optional (``binary/modules.py:96-98``).  Which of them are packed follows
-        ``quantize_moondream`` (``binary/utils.py:14-21``): nothing whose name contains ``lm_head``, nothing in the first
-        ``start_skip`` or last ``last_skip`` blocks ``transformer.h.{i}.`` (the block count is the highest index in the
-        file + 1).  ``select(prefix) -> bool`` replaces that rule.  The file is opened with ``safe_open`` (tensors only,
+        ``quantize_moondream`` (``binary/utils.py:14-21``), which tests the name of the module whose CHILDREN
+        ``linear_to_quantized`` converts (``binary/modules.py:191``): the rule is applied to the layer's PARENT name -
+        no ``lm_head`` in it, and none of ``transformer.h.{i}.`` for the first ``start_skip`` / last ``last_skip`` blocks.
+        (So a Linear that is a direct child of a skipped block, ``transformer.h.0.<linear>``, is converted, as in the
+        reference: its parent ``transformer.h.0`` lacks the trailing dot.  Phi blocks hold their Linears one level
+        deeper, under ``mixer`` / ``mlp``.)  ``n_blocks`` is ``len(transformer.h)``; if not given it is taken to be the
+        highest block index in the file + 1, which is right unless trailing blocks hold no tensors.  ``select(prefix) ->
+        bool`` replaces the rule.  The file is opened with ``safe_open`` (tensors only,
         nothing is executed) and read one layer at a time; prefixes the rule left out are listed in ``arena.skipped``."""
-        import re
-
         from safetensors import safe_open
         with safe_open(path, framework="pt", device="cpu") as f:
             keys = set(f.keys())
-            blocks = [int(mo.group(1)) for key in keys for mo in [re.search(r"transformer\.h\.(\d+)\.", key)] if mo]
-            n_blocks = max(blocks) + 1 if blocks else 0
-            from .utils import layers_to_skip
-            skip = layers_to_skip(n_blocks, start_skip, last_skip)
-            rule = select if select is not None else (lambda p: "lm_head" not in p and not any(s_ in p + "." for s_ in skip))
-            specs, skipped = [], []
-            for key in sorted(keys, key=_natural_key):
-                if not key.endswith(".weights"):
-                    continue
-                prefix = key[: -len(".weights")]
-                if prefix + ".scale" not in keys:
-                    continue
-                if not rule(prefix):
-                    skipped.append(prefix)
-                    continue
+            chosen, skipped = checkpoint_layer_selection(keys, start_skip, last_skip, n_blocks, select)
+            specs = []
+            for prefix in chosen:
+                key = prefix + ".weights"
                 shape = f.get_slice(key).get_shape()
                 if len(shape) != 2:
                     raise ValueError(f"{key}: expected a 2-D latent weight matrix, got shape {shape}")

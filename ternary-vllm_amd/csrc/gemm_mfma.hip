@@ -31,7 +31,8 @@ namespace tvl {
 template <typename TY, bool HAS_BIAS, int ACT, int VEC>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t m, int64_t n,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
-                                                            float clip, int act_begin, TY* __restrict__ y, int64_t ld_y) {
+                                                            float clip, int act_begin, TY* __restrict__ y, int64_t ld_y,
+                                                            const TY* __restrict__ add1, int64_t ld1, const TY* __restrict__ add2, int64_t ld2) {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     const float c = fabsf(clip);
     const int64_t per_row = n / VEC, total = m * per_row, stride = m * n;
@@ -62,6 +63,15 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
             const float a = acc[e];
             out[e] = from_float<TY>(epilogue_ch<HAS_BIAS, ACT>(a, scale[col + e], HAS_BIAS ? bias[col + e] : 0.0f, c, (int)(col + e), act_begin));
         }
+        // optional addends (tvl_ternary_matmul_residual): (y + add1) + add2, every sum rounded to y's type like the unfused sequence
+        if (add1 != nullptr) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) out[e] = from_float<TY>(to_float(out[e]) + to_float(add1[r * ld1 + col + e]));
+            if (add2 != nullptr) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) out[e] = from_float<TY>(to_float(out[e]) + to_float(add2[r * ld2 + col + e]));
+            }
+        }
         TY* dst = y + r * ld_y + col;
         if constexpr (VEC == 4) {
             if constexpr (sizeof(TY) == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(out);
@@ -80,10 +90,18 @@ static int launch_reduce(const float* slab, int splits, int64_t m, int64_t n, co
     int64_t g = ceil_div(vec ? m * (n / 4) : m * n, 256);
     g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
     const dim3 grid((unsigned)g), block(256);
+    const TY *add1 = nullptr, *add2 = nullptr;
+    int64_t ld1 = 0, ld2 = 0;
+    if (tls_residual != nullptr && !tls_residual->consumed && tls_residual->add1 != nullptr && tls_residual->y == (const void*)y &&
+        tls_residual->m == m) {   // the call's addends ride in this epilogue
+        add1 = (const TY*)tls_residual->add1; ld1 = tls_residual->ld1;
+        add2 = (const TY*)tls_residual->add2; ld2 = tls_residual->ld2;
+        tls_residual->consumed = true;
+    }
 #define TVL_RD(HB, ACT)                                                                                                                    \
     do {                                                                                                                                   \
-        if (vec) hipLaunchKernelGGL((splitk_reduce_kernel<TY, HB, ACT, 4>), grid, block, 0, st, slab, splits, m, n, scale, bias, clip, act_begin, y, ld_y); \
-        else hipLaunchKernelGGL((splitk_reduce_kernel<TY, HB, ACT, 1>), grid, block, 0, st, slab, splits, m, n, scale, bias, clip, act_begin, y, ld_y);     \
+        if (vec) hipLaunchKernelGGL((splitk_reduce_kernel<TY, HB, ACT, 4>), grid, block, 0, st, slab, splits, m, n, scale, bias, clip, act_begin, y, ld_y, add1, ld1, add2, ld2); \
+        else hipLaunchKernelGGL((splitk_reduce_kernel<TY, HB, ACT, 1>), grid, block, 0, st, slab, splits, m, n, scale, bias, clip, act_begin, y, ld_y, add1, ld1, add2, ld2);     \
     } while (0)
     if (bias) {
         if (act == TVL_ACT_GELU_TANH) TVL_RD(true, TVL_ACT_GELU_TANH); else TVL_RD(true, TVL_ACT_NONE);
@@ -374,6 +392,38 @@ static size_t slab_bytes(int64_t m, int64_t n, int64_t k) {
         return p2.splits > 1 ? (size_t)p2.splits * (m - m1) * n * sizeof(float) : 0;
     }
     return p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
+}
+
+static int describe_plan(const GemmPlan& p, int64_t m, int64_t n, char* out, size_t len) {
+    const char* kind = p.kind == KIND_BIG ? "gemm_mfma16_kernel 256x256" : p.kind == KIND_MID ? "gemm_mfma16_kernel" : "gemm_mfma_kernel";
+    const int cus = device_cu_count();
+    const bool persist = (p.kind == KIND_BIG && ceil_div(m, 256) * ceil_div(n, 256) > cus) ||
+                         (p.kind == KIND_MID && p.bn == 256 && p.splits == 1 && ceil_div(m, 128) * ceil_div(n, 256) > cus);
+    if (p.kind == KIND_BIG) return snprintf(out, len, "%s%s", kind, persist ? " persistent" : "");
+    if (p.splits > 1) return snprintf(out, len, "%s %dx%d split-k %d + splitk_reduce_kernel", kind, p.bm, p.bn, p.splits);
+    return snprintf(out, len, "%s %dx%d%s", kind, p.bm, p.bn, persist ? " persistent" : "");
+}
+
+void gemm_mfma_describe(int x_dtype, int64_t m, int64_t n, int64_t k, size_t workspace_bytes, char* out, size_t out_len) {
+    if (out_len == 0) return;
+    size_t ws = workspace_bytes;
+    int off = 0;
+    if (x_dtype == TVL_F32) {   // three bf16 planes side by side along k
+        off = snprintf(out, out_len, "split_f32_kernel + ");
+        ws = ws > split_bytes(m, k) ? ws - split_bytes(m, k) : 0;
+        k *= 3;
+    }
+    if (off < 0 || (size_t)off >= out_len) return;
+    const GemmPlan p = plan_gemm(m, n, k, ws);
+    int head_bm = 0;
+    if (const int64_t m1 = tail_split_rows(p, m, n, k, ws, &head_bm)) {
+        int w = snprintf(out + off, out_len - off, "rows 0..%lld: gemm_mfma16_kernel %dx256 persistent; rest: ", (long long)m1, head_bm);
+        if (w < 0 || (size_t)(off + w) >= out_len) return;
+        off += w;
+        describe_plan(plan_gemm(m - m1, n, k, ws), m - m1, n, out + off, out_len - off);
+        return;
+    }
+    describe_plan(p, m, n, out + off, out_len - off);
 }
 
 size_t gemm_mfma_workspace_bytes(int x_dtype, int64_t m, int64_t n, int64_t k) {

@@ -316,11 +316,14 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
             }
     };
     const int st_dst = (st_p & 7) * FS + (st_p >> 3) * 16 + st_row;
-    auto store_phase = [&]() __attribute__((always_inline)) {
+    // the LDS image holds min(total, PS) steps (rows_staged_lds_bytes): steps past the end of k are loaded (clamped) but never stored
+    auto store_phase = [&](int ph) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < PS; ++s)
+            if (ph * PS + s < total) {
 #pragma unroll
-            for (int i = 0; i < MR; ++i) *reinterpret_cast<nts_u32x4*>(xbuf + (s * MR + i) * IMG + st_dst) = st[s][i];
+                for (int i = 0; i < MR; ++i) *reinterpret_cast<nts_u32x4*>(xbuf + (s * MR + i) * IMG + st_dst) = st[s][i];
+            }
     };
     load_phase(0);
     // ---- weight loads of all of this wave's steps: step ph * PS + sw * SPW + q (past the end: the last step again, never used)
@@ -340,7 +343,7 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
                 w[ph][q][t] = make_uint4(v[0], v[1], v[2], v[3]);
             }
     }
-    store_phase();
+    store_phase(0);
     __syncthreads();
 
     floatx4 acc[MR][CTW];
@@ -382,7 +385,7 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
             }
             if (ph + 1 < PH && ph + 1 < nph) {
                 __syncthreads();                                      // everyone has read this phase's image
-                store_phase();
+                store_phase(ph + 1);
                 __syncthreads();
             }
         }

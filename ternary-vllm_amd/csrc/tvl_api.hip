@@ -21,6 +21,62 @@ void set_error(const char* fmt, ...) {
 
 static inline bool float_dtype(int dt) { return dt == TVL_F32 || dt == TVL_F16 || dt == TVL_BF16; }
 
+thread_local ResidualArgs* tls_residual = nullptr;
+
+// y = (y + add1) + add2 over an [m, n] matrix, each sum rounded to y's type: four elements per thread where rows allow 16-byte /
+// 8-byte accesses, else one
+template <typename TY, int VEC>
+__global__ void __launch_bounds__(256) add_rows_kernel(TY* __restrict__ y, int64_t m, int64_t n, int64_t ld_y, const TY* __restrict__ add1, int64_t ld1,
+                                                       const TY* __restrict__ add2, int64_t ld2) {
+    const int64_t per_row = n / VEC, total = m * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / per_row, col = (i - r * per_row) * VEC;
+        TY v[VEC], a[VEC], b[VEC];
+        if constexpr (VEC == 4) {
+            typedef uint32_t raw_t __attribute__((ext_vector_type(sizeof(TY))));   // 4 elements: 16 bytes (f32) or 8 bytes (16-bit types)
+            *reinterpret_cast<raw_t*>(v) = *reinterpret_cast<const raw_t*>(y + r * ld_y + col);
+            *reinterpret_cast<raw_t*>(a) = *reinterpret_cast<const raw_t*>(add1 + r * ld1 + col);
+            if (add2) *reinterpret_cast<raw_t*>(b) = *reinterpret_cast<const raw_t*>(add2 + r * ld2 + col);
+        } else {
+            v[0] = y[r * ld_y + col]; a[0] = add1[r * ld1 + col];
+            if (add2) b[0] = add2[r * ld2 + col];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            v[e] = from_float<TY>(to_float(v[e]) + to_float(a[e]));
+            if (add2) v[e] = from_float<TY>(to_float(v[e]) + to_float(b[e]));
+        }
+        if constexpr (VEC == 4) {
+            typedef uint32_t raw_t __attribute__((ext_vector_type(sizeof(TY))));
+            *reinterpret_cast<raw_t*>(y + r * ld_y + col) = *reinterpret_cast<const raw_t*>(v);
+        } else {
+            y[r * ld_y + col] = v[0];
+        }
+    }
+}
+
+template <typename TY>
+static int launch_add_rows_t(TY* y, int64_t m, int64_t n, int64_t ld_y, const TY* add1, int64_t ld1, const TY* add2, int64_t ld2, hipStream_t st) {
+    const size_t va = 4 * sizeof(TY);
+    const bool vec = n % 4 == 0 && aligned(y, va) && aligned(add1, va) && (add2 == nullptr || aligned(add2, va)) && (ld_y * sizeof(TY)) % va == 0 &&
+                     (ld1 * sizeof(TY)) % va == 0 && (ld2 * sizeof(TY)) % va == 0;
+    int64_t g = ceil_div(vec ? m * (n / 4) : m * n, 256);
+    g = g < 1 ? 1 : (g > 8192 ? 8192 : g);
+    if (vec) hipLaunchKernelGGL((add_rows_kernel<TY, 4>), dim3((unsigned)g), dim3(256), 0, st, y, m, n, ld_y, add1, ld1, add2, ld2);
+    else hipLaunchKernelGGL((add_rows_kernel<TY, 1>), dim3((unsigned)g), dim3(256), 0, st, y, m, n, ld_y, add1, ld1, add2, ld2);
+    TVL_LAUNCH_CHECK();
+    return TVL_OK;
+}
+
+int launch_add_rows(void* y, int y_dtype, int64_t m, int64_t n, int64_t ld_y, const void* add1, int64_t ld1, const void* add2, int64_t ld2, hipStream_t st) {
+    switch (y_dtype) {
+        case TVL_F32: return launch_add_rows_t((float*)y, m, n, ld_y, (const float*)add1, ld1, (const float*)add2, ld2, st);
+        case TVL_F16: return launch_add_rows_t((f16*)y, m, n, ld_y, (const f16*)add1, ld1, (const f16*)add2, ld2, st);
+        case TVL_BF16: return launch_add_rows_t((bf16_t*)y, m, n, ld_y, (const bf16_t*)add1, ld1, (const bf16_t*)add2, ld2, st);
+        default: set_error("ternary_matmul_residual: unsupported output dtype %d", y_dtype); return TVL_ERR_INVALID;
+    }
+}
+
 }  // namespace tvl
 
 using namespace tvl;
@@ -222,6 +278,64 @@ int tvl_ternary_matmul_act_from(const void* x, int x_dtype, int64_t m, int64_t k
                            (hipStream_t)stream, true);
 }
 
+int tvl_ternary_matmul_residual(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
+                                const float* scale, const float* bias, float clip, int act, int64_t act_begin_channel, const void* add1,
+                                int64_t ld_add1, const void* add2, int64_t ld_add2, void* y, int y_dtype, int64_t ld_y, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (add1 == nullptr && add2 != nullptr) { add1 = add2; ld_add1 = ld_add2; add2 = nullptr; ld_add2 = 0; }
+    if (add1 == nullptr)
+        return tvl_ternary_matmul_act_from(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin_channel, y, y_dtype, ld_y, workspace,
+                                           workspace_bytes, stream);
+    TVL_REQUIRE(n >= 0 && m >= 0, "ternary_matmul_residual: negative shape");
+    if (ld_add1 == 0) ld_add1 = n;
+    if (ld_add2 == 0) ld_add2 = n;
+    if (ld_y == 0) ld_y = n;
+    TVL_REQUIRE(ld_add1 >= n && ld_add2 >= n, "ternary_matmul_residual: addend row stride %lld / %lld < n=%lld", (long long)ld_add1, (long long)ld_add2, (long long)n);
+    TVL_REQUIRE(float_dtype(y_dtype), "ternary_matmul_residual: output dtype must be f32/f16/bf16, got %d", y_dtype);
+    TVL_REQUIRE(aligned(add1, dtype_size(y_dtype)) && aligned(add2, dtype_size(y_dtype)), "ternary_matmul_residual: misaligned addend pointer");
+    // the product is written to y before the addends are read (unless the split-K reduction takes them): y must not be an addend
+    TVL_REQUIRE(add1 != y && add2 != y, "ternary_matmul_residual: an addend is the output buffer itself (the product is written before the addends are read)");
+    ResidualArgs res{add1, ld_add1, add2, ld_add2, y, m, false};
+    tls_residual = &res;
+    const int rc = tvl_ternary_matmul_act_from(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin_channel, y, y_dtype, ld_y, workspace,
+                                               workspace_bytes, stream);
+    tls_residual = nullptr;
+    if (rc != TVL_OK || res.consumed || m == 0 || n == 0) return rc;
+    return launch_add_rows(y, y_dtype, m, n, ld_y, add1, ld_add1, add2, ld_add2, (hipStream_t)stream);
+}
+
+int tvl_ternary_matmul_route(int x_dtype, int64_t m, int64_t n, int64_t k, size_t workspace_bytes, char* out, size_t out_len) {
+    TVL_REQUIRE(out != nullptr && out_len > 0, "ternary_matmul_route: no output buffer");
+    TVL_REQUIRE(float_dtype(x_dtype) && m > 0 && n > 0 && k > 0, "ternary_matmul_route: bad dtype or shape");
+    // dense, well-aligned operands: pointers that pass every alignment test, never dereferenced
+    const void* x = reinterpret_cast<const void*>(uintptr_t(1) << 20);
+    const uint8_t* pw = reinterpret_cast<const uint8_t*>(uintptr_t(2) << 20);
+    const void* ws = workspace_bytes ? reinterpret_cast<const void*>(uintptr_t(3) << 20) : nullptr;
+    const int64_t ld_x = k, ld_pw = ceil_div(k, 4);
+    const char* name = nullptr;
+    if (gemm_rows_shared_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, ws, workspace_bytes)) name = "gemm_rows_shared_kernel (+ splitk_reduce_kernel when k is split)";
+    else if (gemm_rows_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, ws, workspace_bytes)) name = "gemm_rows_staged_kernel / gemm_rows_kernel (one launch)";
+    else if (gemv_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw)) name = "gemv_kernel";
+    else if (gemm_stream_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, ws, workspace_bytes)) name = "gemm_stream_kernel + splitk_reduce_kernel";
+    else if (gemm_skinny_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw)) name = "gemm_skinny_kernel + splitk_reduce_kernel";
+    if (name != nullptr) { snprintf(out, out_len, "%s", name); return TVL_OK; }
+    if (gemm_mfma_supported(x, x_dtype, m, k, ld_x, pw, n, ld_pw, ws, workspace_bytes)) {
+        gemm_mfma_describe(x_dtype, m, n, k, workspace_bytes, out, out_len);
+        return TVL_OK;
+    }
+    if ((double)m * (double)n * (double)k >= PAD_ROUTE_MIN_WORK && ws && workspace_bytes >= pad_route_bytes(x_dtype, m, n, k)) {
+        const int w = snprintf(out, out_len, "pad_rows_kernel + pad_packed_kernel + ");
+        if (w > 0 && (size_t)w < out_len) {
+            const int64_t kp = round_up64(k);
+            const size_t used = align256((size_t)m * kp * dtype_size(x_dtype)) + align256((size_t)n * (kp / 4));
+            return tvl_ternary_matmul_route(x_dtype, m, n, kp, workspace_bytes - used, out + w, out_len - w);
+        }
+        return TVL_OK;
+    }
+    snprintf(out, out_len, "gemm_generic_kernel");
+    return TVL_OK;
+}
+
 }  // extern "C"
 
 // ---- the matmul for callers that cannot allocate ------------------------------------------------------------------
@@ -264,13 +378,14 @@ int tvl_ternary_matmul_noalloc(const void* x, int x_dtype, int64_t m, int64_t k,
                 "ternary_matmul_noalloc: m=%lld n=%lld k=%lld (dtype %d) needs %zu bytes of scratch memory, the built-in buffer holds %zu: "
                 "use tvl_ternary_matmul with a caller-owned workspace, or split the rows over several calls",
                 (long long)m, (long long)n, (long long)k, x_dtype, need, (size_t)TVL_NOALLOC_SCRATCH_BYTES);
+    // Looked up on every call, whatever the size (one atomic load after the first): a call with m = 0 before a stream capture starts is
+    // enough to keep the one-time hipGetSymbolAddress (a runtime call that is not a stream operation) out of the capture.
     void* ws = nullptr;
-    if (need > 0) {
-        const int rc = current_device_scratch(&ws);
-        if (rc != TVL_OK) return rc;
-    }
-    return tvl_ternary_matmul_act_from(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin_channel, y, y_dtype, ld_y, ws,
-                                       need > 0 ? (size_t)TVL_NOALLOC_SCRATCH_BYTES : 0, stream);
+    if (const int rc = current_device_scratch(&ws); rc != TVL_OK) return rc;
+    // `need` bytes, not the whole array: the planners then see exactly what tvl_ternary_matmul_act_from sees with a workspace of
+    // tvl_ternary_matmul_workspace_bytes_for() bytes, so both entry points choose the same kernels and k splits
+    return tvl_ternary_matmul_act_from(x, x_dtype, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin_channel, y, y_dtype, ld_y,
+                                       need > 0 ? ws : nullptr, need, stream);
 }
 
 int tvl_sign_pack_bits(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, uint32_t* xb, int64_t ld_xb, void* stream) {

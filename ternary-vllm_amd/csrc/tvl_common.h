@@ -83,11 +83,17 @@ template <int MODE> __device__ __forceinline__ uint32_t quantize_code(float w, f
 }
 
 // epilogue shared by every matmul kernel: two roundings (multiply, then add), clip, activation
+// tanh-GELU, 0.5 x (1 + tanh(u)) with u = sqrt(2/pi) (x + 0.044715 x^3).  0.5 (1 + tanh(u)) = 1 - 1 / (exp(2u) + 1), so one hardware
+// exponential and one hardware reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each) replace the library tanhf (~3x the instructions; the
+// epilogue of a 25216 x 3072 x 768 product spent a third of the launch there).  Absolute error <= |x| * 2e-7 against the exact form
+// (tests: <= 1e-5 against a float64 evaluation); x = +-inf and NaN behave like the exact form (exp -> inf / 0, NaN propagates).
 __device__ __forceinline__ float gelu_tanh_f32(float x) {
     const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
     const float k1 = 0.044715f;
-    float inner = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(inner));
+    const float inner = k0 * (x + k1 * x * x * x);
+    const float e = __builtin_amdgcn_exp2f(inner * 2.8853900817779268f);   // exp(2 u) = 2^(2 u log2(e))
+    const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+    return x * (1.0f - r);   // (not x - x r: +inf must stay +inf)
 }
 
 template <bool HAS_BIAS, int ACT>

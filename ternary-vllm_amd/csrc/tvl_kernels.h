@@ -42,6 +42,17 @@ int launch_split_f32_rows(const float* x, int64_t m, int64_t k, int64_t ld_x, ui
 int launch_splitk_reduce(const float* slab, int splits, int64_t m, int64_t n, const float* scale, const float* bias, float clip,
                          int act, int act_begin, void* y, int y_dtype, int64_t ld_y, hipStream_t st);
 
+// Addends of tvl_ternary_matmul_residual, y = (y + add1) + add2 in y's type, for the duration of one call on the calling thread:
+// launch_splitk_reduce takes them into its epilogue and marks them consumed when it writes the call's WHOLE output (y, m as
+// recorded here: a product that runs as two row ranges is not); if no kernel of the route did, the entry point finishes with
+// launch_add_rows.  (A thread-local hand-over instead of two more arguments on every launcher.)
+struct ResidualArgs { const void* add1; int64_t ld1; const void* add2; int64_t ld2; const void* y; int64_t m; bool consumed; };
+extern thread_local ResidualArgs* tls_residual;   // tvl_api.hip; nullptr outside such a call
+// y[m, n] = (y + add1) + add2, each sum rounded to y's type (add2 may be NULL)
+int launch_add_rows(void* y, int y_dtype, int64_t m, int64_t n, int64_t ld_y, const void* add1, int64_t ld1, const void* add2, int64_t ld2, hipStream_t st);
+// host-side description of the tile plan launch_gemm_mfma would choose (tvl_ternary_matmul_route)
+void gemm_mfma_describe(int x_dtype, int64_t m, int64_t n, int64_t k, size_t workspace_bytes, char* out, size_t out_len);
+
 // gemm_mid.hip: 128-row tiles of the 16x16x32 kernel (with or without split-K into float32 slabs at `slab`)
 int launch_gemm_mid(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ld_x, const uint8_t* pw, int64_t n, int64_t ld_pw,
                     const float* scale, const float* bias, float clip, int act, int act_begin, void* y, int y_dtype, int64_t ld_y,

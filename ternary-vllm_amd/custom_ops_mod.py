@@ -49,6 +49,9 @@ SIGNATURES = {
                                     _c_int, _c_vp, _c_int, _c_i64, _c_vp, _c_sz, _c_vp]),
     "tvl_ternary_matmul_act_from": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_f32,
                                              _c_int, _c_i64, _c_vp, _c_int, _c_i64, _c_vp, _c_sz, _c_vp]),
+    "tvl_ternary_matmul_residual": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_f32,
+                                             _c_int, _c_i64, _c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_int, _c_i64, _c_vp, _c_sz, _c_vp]),
+    "tvl_ternary_matmul_route": (_c_int, [_c_int, _c_i64, _c_i64, _c_i64, _c_sz, ctypes.c_char_p, _c_sz]),
     "tvl_ternary_matmul_noalloc": (_c_int, [_c_vp, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_f32,
                                             _c_int, _c_i64, _c_vp, _c_int, _c_i64, _c_vp]),
     "tvl_noalloc_scratch_bytes": (_c_sz, []),
@@ -365,8 +368,9 @@ def _matmul_workspace(device: torch.device, stream: int, x_dtype: int, m: int, n
 
 def ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias: Optional[torch.Tensor], clip_val: float,
                    activation: Optional[str] = None, out_dtype: Optional[torch.dtype] = None,
-                   out: Optional[torch.Tensor] = None, act_begin: int = 0) -> torch.Tensor:
-    """``act(clip((x @ unpack(pw)^T) * scale + bias, +-clip_val))``.
+                   out: Optional[torch.Tensor] = None, act_begin: int = 0, residual: Optional[torch.Tensor] = None,
+                   residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(clip((x @ unpack(pw)^T) * scale + bias, +-clip_val))``  (``+ residual + residual2`` when given).
 
     ``ops.ternary_matmul(x, pw, scale, bias, clip)`` at ``impl/tf/moondream/ternary.py:281``; the
     order of operations is ``binary/modules.py:104-108``.  ``x``: ``[..., K]`` f16 / bf16 / f32;
@@ -374,6 +378,9 @@ def ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias:
     (the reference applies it after the op, ``ternary.py:298-299``) is fused into the kernel.
     ``act_begin``: output channels below it get no activation - two Dense layers on one input (the Phi
     block's Wqkv and fc1, ``impl/tf/moondream/layers.py:334-347``) stored as one packed matrix, one launch.
+    ``residual`` / ``residual2``: ``[..., N]`` tensors of the output's dtype added after the activation, ``(y + residual) +
+    residual2`` with every sum rounded to the output dtype - the bits of ``y + residual + residual2`` in torch: the decoder
+    block's ``attn_outputs + feed_forward_hidden_states + residual`` (``impl/tf/moondream/layers.py:347``) as part of fc2's call.
     """
     x = _gpu(x, "ternary_matmul(x)")
     if activation not in _ACTS:
@@ -400,9 +407,26 @@ def ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias:
     if act_begin < 0 or act_begin > n:
         raise ValueError(f"ternary_matmul: act_begin={act_begin} outside [0, {n}]")
 
+    adds = []
+    for name, r in (("residual", residual), ("residual2", residual2)):
+        if r is None:
+            continue
+        r = _gpu(r, f"ternary_matmul({name})")
+        if r.dtype != y.dtype or r.device != x.device or r.shape[-1] != n or r.numel() != m * n:
+            raise ValueError(f"ternary_matmul: {name} must be a [..., {n}] {y.dtype} tensor with {m} rows on {x.device}, got {tuple(r.shape)} {r.dtype}")
+        adds.append(_rows(r.reshape(-1, n), f"ternary_matmul({name})"))
+
     def launch():
         stream = _stream(x)
         ws_ptr, ws_bytes = _matmul_workspace(x.device, stream, xdt, m, n, k)
+        if adds:
+            a1, a2 = adds[0], adds[1] if len(adds) > 1 else None
+            _check(_lib.tvl_ternary_matmul_residual(x2.data_ptr(), xdt, m, k, _ld(x2), pw.data_ptr(), n, _ld(pw),
+                                                    scale.data_ptr(), bias.data_ptr() if bias is not None else None, float(clip_val),
+                                                    _ACTS[activation], act_begin, a1.data_ptr(), _ld(a1),
+                                                    a2.data_ptr() if a2 is not None else None, _ld(a2) if a2 is not None else 0,
+                                                    y.data_ptr(), _dt(y, "ternary_matmul(out)"), _ld(y), ws_ptr, ws_bytes, stream))
+            return
         _check(_lib.tvl_ternary_matmul_act_from(x2.data_ptr(), xdt, m, k, _ld(x2), pw.data_ptr(), n, _ld(pw),
                                                 scale.data_ptr(), bias.data_ptr() if bias is not None else None, float(clip_val),
                                                 _ACTS[activation], act_begin, y.data_ptr(), _dt(y, "ternary_matmul(out)"), _ld(y),
@@ -416,6 +440,17 @@ def ternary_matmul(x: torch.Tensor, pw: torch.Tensor, scale: torch.Tensor, bias:
     if out is not None:
         return out
     return y if len(lead) == 1 else y.reshape(*lead, n)
+
+
+def matmul_route(x_dtype: torch.dtype, m: int, n: int, k: int, workspace_bytes: Optional[int] = None) -> str:
+    """Names of the kernels ``ternary_matmul`` launches for dense operands of this shape (``tvl_ternary_matmul_route``); the
+    workspace defaults to what ``ternary_matmul`` itself provides."""
+    xdt = _DTYPES[x_dtype]
+    if workspace_bytes is None:
+        workspace_bytes = int(_lib.tvl_ternary_matmul_workspace_bytes_for(xdt, m, n, k))
+    buf = ctypes.create_string_buffer(512)
+    _check(_lib.tvl_ternary_matmul_route(xdt, m, n, k, workspace_bytes, buf, len(buf)))
+    return buf.value.decode()
 
 
 class PreparedMatmul:

@@ -38,6 +38,7 @@ class DecoderConfig:
     clip: float = 100.0
     max_len: int = 1024
     fuse_qkv_fc1: bool = True     # Wqkv | fc1 as one packed matrix, tanh-GELU from channel 3 * hidden on
+    fuse_residual: bool = True    # the block's closing attn + mlp + residual as part of fc2's call (same bits as the separate additions)
 
     @property
     def head_dim(self) -> int:
@@ -78,11 +79,14 @@ class PackedLinear:
         f.out_features, f.in_features = linear.out_features + activated.out_features, linear.in_features
         return f
 
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.ternary_matmul(x, self.pw, self.scale, self.bias, self.clip, activation=self.activation, act_begin=self.act_begin)
+    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return ops.ternary_matmul(x, self.pw, self.scale, self.bias, self.clip, activation=self.activation, act_begin=self.act_begin,
+                                  residual=residual, residual2=residual2)
 
-    def reference(self, x: torch.Tensor) -> torch.Tensor:
-        """The same layer with dense float32 weights in plain torch (``binary/modules.py:101-109`` order)."""
+    def reference(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same layer with dense float32 weights in plain torch (``binary/modules.py:101-109`` order); the optional addends
+        are added by the caller's dtype rules (see TernaryDecoderStack._block)."""
+        assert residual is None and residual2 is None, "the dense twin returns the product; its caller adds"
         w = self.ternary.to(x.device).float()
         y = x.float() @ w.t()
         y = y * self.scale + self.bias
@@ -144,6 +148,7 @@ class TernaryDecoderStack:
         self._static_in = None
         self._static_out = None
         self.linear = lambda layer, x: layer(x)    # swapped for PackedLinear.reference in tests
+        self.fused_calls = True                    # tests that swap `linear` for the dense twin turn this off too
 
     # ------------------------------------------------------------------ one block, any number of new tokens
     def _block(self, i: int, blk: Block, h: torch.Tensor, positions: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -168,6 +173,9 @@ class TernaryDecoderStack:
         attn_out = self.linear(blk.out_proj, att).to(h.dtype)
         if fc1_out is None:
             fc1_out = self.linear(blk.fc1, x).to(h.dtype)
+        if self.cfg.fuse_residual and self.fused_calls:
+            # layers.py:347 `attn_outputs + feed_forward_hidden_states + residual` = (mlp + attn) + h, inside fc2's call
+            return blk.fc2(fc1_out, residual=attn_out, residual2=h)
         mlp = self.linear(blk.fc2, fc1_out).to(h.dtype)
         return attn_out + mlp + h
 

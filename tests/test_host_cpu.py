@@ -66,6 +66,46 @@ def test_row_bytes_and_sharding_helpers():
     assert tv.utils.layers_to_skip(24, 1, 1) == ["transformer.h.0.", "transformer.h.23."]  # convert.py:72
 
 
+def test_checkpoint_layer_selection_follows_the_parent_module_rule():
+    """The converter's layer choice against the reference's walk (binary/utils.py:17-21 tests the name of the module whose direct
+    children binary/modules.py:191 converts), re-enacted on a module tree with torch alone: Phi-shaped blocks plus a Linear that is a
+    DIRECT child of a skipped block and a head."""
+    import ternary_vllm_amd as tv
+    from torch import nn
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mixer = nn.ModuleDict({"Wqkv": nn.Linear(4, 4), "out_proj": nn.Linear(4, 4)})
+            self.mlp = nn.ModuleDict({"fc1": nn.Linear(4, 4), "fc2": nn.Linear(4, 4)})
+            self.gate = nn.Linear(4, 4)   # direct child of the block
+
+    model = nn.Module()
+    model.transformer = nn.Module()
+    model.transformer.h = nn.ModuleList([Block() for _ in range(4)])
+    model.lm_head = nn.ModuleDict({"linear": nn.Linear(4, 4)})
+    model.proj = nn.Linear(4, 4)       # direct child of the root
+    for start_skip, last_skip in [(1, 0), (1, 1), (0, 0), (2, 1)]:
+        skip = [f"transformer.h.{i}." for i in range(start_skip)] + [f"transformer.h.{4 - 1 - i}." for i in range(last_skip)]
+        want = []                       # what the reference's loop converts
+        for name, mod in model.named_modules():
+            if "lm_head" not in name and not any(s in name for s in skip):
+                want += [(name + "." if name else "") + cn for cn, child in mod.named_children() if isinstance(child, nn.Linear)]
+        keys = []
+        for name, mod in model.named_modules():
+            if isinstance(mod, nn.Linear):
+                keys += [name + ".weights", name + ".scale", name + ".bias"]
+        keys += ["transformer.embd.wte.weight", "orphan.weights"]          # not quantized layers: no .scale beside them
+        chosen, skipped = tv.conversion.checkpoint_layer_selection(keys, start_skip, last_skip, n_blocks=4)
+        assert sorted(chosen) == sorted(want), (start_skip, last_skip)
+        assert sorted(chosen + skipped) == sorted(k[:-8] for k in keys if k.endswith(".weights") and k != "orphan.weights")
+        if start_skip:
+            assert "transformer.h.0.gate" in chosen and "transformer.h.0.mlp.fc1" in skipped   # the reference's quirk, kept
+        assert "lm_head.linear" in skipped and "proj" in chosen
+    # block count inferred from the keys when not given
+    assert tv.conversion.checkpoint_layer_selection(keys, 0, 1)[1] == tv.conversion.checkpoint_layer_selection(keys, 0, 1, n_blocks=4)[1]
+
+
 def test_c_port_matches_numpy_oracle():
     """The C/OpenMP restatement (CPU baseline of the benchmark) against the numpy oracle."""
     from __graft_entry__ import build_oracle

@@ -385,6 +385,7 @@ def test_decode_harness_matches_dense_reference_and_graph_replay(dev):
         assert len(st.blocks[0].linears()) == (3 if cfg.fuse_qkv_fc1 else 4)
         if reference:
             st.linear = lambda layer, x: layer.reference(x)
+            st.fused_calls = False
         outs = [st.prefill(prompt)]
         if graph:
             st.capture_decode(toks[0])
@@ -400,6 +401,41 @@ def test_decode_harness_matches_dense_reference_and_graph_replay(dev):
     for a, b in zip(packed, replay):
         assert torch.equal(a, b)
     for a, b in zip(packed, run(False, False, cfg_unfused)):
+        assert torch.equal(a, b)
+    # the block's closing sum inside fc2's call (the default) = the three tensors added by torch
+    cfg_sum = dh.DecoderConfig(hidden=256, heads=4, intermediate=1024, blocks=2, max_len=64, fuse_residual=False)
+    for a, b in zip(packed, run(False, False, cfg_sum)):
+        assert torch.equal(a, b)
+
+
+def test_decode_harness_at_the_models_dimensions(dev):
+    """The harness at moondream2's text-model dimensions (impl/tf/moondream/layers.py:385-405: hidden 2048, 32 heads, intermediate
+    8192), two blocks, batch 256, f16: a short prefill and two single-token steps against the same stack with dense float32
+    torch layers (same f16 tensors between the layers), and the fused forms (Wqkv | fc1 as one product, the closing sum inside
+    fc2's call) against the unfused ones bit for bit."""
+    from ternary_vllm_amd import decode_harness as dh
+    kw = dict(hidden=2048, heads=32, intermediate=8192, blocks=2, max_len=16)
+    torch.manual_seed(5)
+    batch = 256
+    prompt = torch.randn(batch, 3, 2048, device=dev).half()
+    toks = [torch.randn(batch, 1, 2048, device=dev).half() for _ in range(2)]
+
+    def run(reference, **cfg_kw):
+        st = dh.TernaryDecoderStack(dh.DecoderConfig(**kw, **cfg_kw), batch=batch, device=dev, dtype=torch.float16, seed=21)
+        if reference:
+            st.linear = lambda layer, x: layer.reference(x)
+            st.fused_calls = False
+        outs = [st.prefill(prompt)] + [st.decode_step(t).clone() for t in toks]
+        return outs
+
+    packed, dense = run(False), run(True)
+    for a, b in zip(packed, dense):
+        assert a.shape == b.shape and a.dtype == torch.float16
+        # both stacks round to f16 between layers; the packed products differ from the dense float32 ones by summation order only
+        err = float((a.float() - b.float()).abs().max())
+        assert err <= 4e-3 * max(1.0, float(b.float().abs().max())), err
+    plain = run(False, fuse_qkv_fc1=False, fuse_residual=False)
+    for a, b in zip(packed, plain):
         assert torch.equal(a, b)
 
 

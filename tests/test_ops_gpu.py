@@ -693,3 +693,63 @@ def test_errors(ops, dev):
     assert ops.pack_fn(torch.zeros((0, 8), dtype=torch.int8, device=dev)).shape == (0, 2)
     # the process survives all of the above and still computes
     assert float(ops.ternary_matmul(x + 1, pw + 0xAA, s, None, 1e4).sum()) == 4 * 8 * 64
+
+
+# ------------------------------------------------------------------------------ the product with the block's closing sum
+
+@pytest.mark.parametrize("m,n,k", [(1, 2048, 2048), (2, 2048, 8192), (16, 2048, 2048), (24, 2048, 8192), (64, 512, 4096), (256, 2048, 2048),
+                                   (256, 2048, 8192), (300, 1024, 4096), (745, 2048, 2048), (70, 96, 250)])
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+def test_matmul_residual_matches_oracle_and_the_separate_additions(ops, dev, m, n, k, dtype):
+    """tvl_ternary_matmul_residual on every family of kernels (one and two rows, few rows in one launch and with a k split, 128-row
+    tiles with and without a k split, an odd k): equal to the oracle twin, and to the product followed by torch's additions."""
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    rng = np.random.default_rng(m + n + k)
+    x = rng.integers(-64, 65, size=(m, k)).astype(np.float32) / 64.0
+    pw = rng.integers(0, 171, size=(n, (k + 3) // 4)).astype(np.uint8)
+    if k % 4:
+        pw[:, -1] = (pw[:, -1] & ((1 << (2 * (k % 4))) - 1)) | (0x55 & ~((1 << (2 * (k % 4))) - 1))   # pad codes 1
+    scale = (rng.integers(4, 13, size=n) / 8.0).astype(np.float32)
+    bias = (rng.integers(-16, 17, size=n) / 8.0).astype(np.float32)
+    a1 = O.round_to(rng.normal(size=(m, n)).astype(np.float32) * 3, dtype)
+    a2 = O.round_to(rng.normal(size=(m, n)).astype(np.float32) * 3, dtype)
+    t = lambda a, d=None: torch.from_numpy(a).to(dev) if d is None else torch.from_numpy(a).to(dev).to(d)
+    xt, pwt, st, bt, a1t, a2t = t(x, tdt), t(pw), t(scale), t(bias), t(a1, tdt), t(a2, tdt)
+    for adds in ((a1, a2), (a1, None)):
+        got = ops.ternary_matmul(xt, pwt, st, bt, 100.0, residual=a1t, residual2=a2t if adds[1] is not None else None)
+        want = O.ternary_matmul_residual(x, pw, scale, bias, 100.0, adds[0], adds[1], out=dtype, k=k)
+        assert got.dtype == tdt
+        assert np.array_equal(got.float().cpu().numpy(), want), (m, n, k, dtype)
+        plain = ops.ternary_matmul(xt, pwt, st, bt, 100.0) + a1t
+        if adds[1] is not None:
+            plain = plain + a2t
+        assert torch.equal(got, plain)
+    # the activation comes before the sums
+    got = ops.ternary_matmul(xt, pwt, st, bt, 100.0, activation="gelu_tanh", act_begin=n // 2, residual=a1t)
+    assert torch.equal(got, ops.ternary_matmul(xt, pwt, st, bt, 100.0, activation="gelu_tanh", act_begin=n // 2) + a1t)
+
+
+def test_matmul_residual_argument_errors(ops, dev):
+    x = torch.zeros(4, 64, device=dev).half()
+    pw = torch.zeros(8, 16, dtype=torch.uint8, device=dev)
+    s = torch.ones(8, device=dev)
+    with pytest.raises(ValueError):
+        ops.ternary_matmul(x, pw, s, None, 1.0, residual=torch.zeros(4, 8, device=dev))             # wrong dtype
+    with pytest.raises(ValueError):
+        ops.ternary_matmul(x, pw, s, None, 1.0, residual=torch.zeros(4, 9, device=dev).half())      # wrong shape
+    with pytest.raises(ValueError):
+        ops.ternary_matmul(x, pw, s, None, 1.0, residual=torch.zeros(4, 8).half())                  # not on the GPU
+    buf = torch.zeros(4, 8, device=dev).half()
+    with pytest.raises(ValueError, match="output buffer"):
+        ops.ternary_matmul(x, pw, s, None, 1.0, residual=buf, out=buf)                               # the output as its own addend
+
+
+def test_matmul_route_names_the_kernels(ops):
+    r = ops.matmul_route
+    assert "256x256" in r(torch.float16, 4096, 4096, 4096)
+    assert "gemv_kernel" in r(torch.float16, 1, 4096, 4096)
+    assert "gemm_rows" in r(torch.float16, 16, 4096, 4096)
+    assert "split-k" in r(torch.float16, 256, 4096, 4096) and "splitk_reduce_kernel" in r(torch.float16, 256, 4096, 4096)
+    assert "split_f32_kernel" in r(torch.float32, 4096, 4096, 4096)
+    assert "pad_rows_kernel" in r(torch.float16, 729, 1152, 4304)
+    assert r(torch.float16, 3, 7, 5) == "gemm_generic_kernel"

@@ -65,10 +65,41 @@ def test_noalloc_matches_workspace_entry_point_twice_in_a_row(ops, dev):
             assert need <= limit
             used += need > 0
     assert used >= 6, "the shapes above are meant to need scratch memory"
+    # random data (sums that depend on the order of addition: any difference in kernel choice or k split would show), one shape per
+    # user of the scratch memory
+    for (m, n, k, xdt) in [(12, 2048, 16384, torch.float16), (300, 1024, 4096, torch.float16), (200, 768, 1024, torch.float32),
+                           (400, 600, 1000, torch.bfloat16), (40, 6144, 2048, torch.float16), (2, 8192, 8192, torch.bfloat16)]:
+        _both(ops, dev, m, n, k, xdt, grid=False)
     # the fused activation from a channel on, random data, and a shape that needs no scratch at all
     _both(ops, dev, 12, 1024, 8192, torch.float16, act=ops.ACT_GELU_TANH, act_begin=300, grid=False)
     assert _both(ops, dev, 4096, 4096, 256, torch.float16) == 0
     _both(ops, dev, 1, 512, 1024, torch.float16)
+
+
+def test_noalloc_leaves_the_devices_free_memory_unchanged(ops, dev):
+    """hipMemGetInfo's free bytes (what a hipMalloc / hipFree inside the library would move; torch's own counters only see torch's
+    allocator) before and after calls that use the scratch memory, after a warm-up call of each kind."""
+    lib = ops._lib
+    stream = torch.cuda.current_stream().cuda_stream
+    shapes = [(12, 2048, 16384, torch.float16), (300, 1024, 4096, torch.float16), (200, 768, 1024, torch.float32), (400, 600, 1000, torch.float16)]
+    probs = []
+    for (m, n, k, xdt) in shapes:
+        _, _, _, _, xt, pwt, st, bt = _problem(dev, 7 + m, m, n, k, xdt)
+        probs.append((m, n, k, ops._DTYPES[xdt], xt, pwt, st, bt, torch.empty((m, n), dtype=torch.float32, device=dev)))
+
+    def run_all():
+        for (m, n, k, xd, xt, pwt, st, bt, y) in probs:
+            rc = lib.tvl_ternary_matmul_noalloc(xt.data_ptr(), xd, m, k, 0, pwt.data_ptr(), n, 0, st.data_ptr(), bt.data_ptr(), ctypes.c_float(100.0),
+                                                0, 0, y.data_ptr(), ops.F32, 0, stream)
+            assert rc == 0, lib.tvl_last_error()
+
+    run_all()                                   # warm-up: code objects loaded, the scratch address looked up
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(dev)[0]
+    for _ in range(3):
+        run_all()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free_before
 
 
 def test_noalloc_rejects_shapes_beyond_the_builtin_buffer(ops, dev):
