@@ -35,6 +35,7 @@
  *   TVL_MID_PERSIST=0|1                pin the persistent form of the 128 x 256 tile off / on
  *   TVL_ROWS_STAGED=0|2                few-row kernel with x staged once in LDS: off / wherever it fits
  *   TVL_ROWS_SHARED=<splits>|-1        few-row kernel for larger layers: pin its k split / off;  TVL_ROWS_SHARED_ANY=1 lifts its size rules
+ *   TVL_ROWS_BLOCKS=0|2                the same kernel on blocks of 64 rows (65 .. 512 rows, small layers): off / wherever it fits
  *   TVL_GEMV=0|2                       one- and two-row kernel: off / wherever it can run
  */
 #ifndef TVL_H_

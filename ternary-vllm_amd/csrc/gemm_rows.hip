@@ -169,6 +169,7 @@ gemm_rows_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const uin
 // activation traffic (m k n / 8 bytes) outgrows the weight stream: larger layers go to gemm_rows_shared_kernel below.  It is used
 // where it wins: 3 .. 16 rows (one or two rows go to the table-lookup kernel) up to m n k = 3e8, and 17 .. 32 rows on small layers.
 static bool rows_use_staged(int64_t m, int64_t n, int64_t k);
+static bool rows_use_blocks(int64_t m, int64_t n, int64_t k);
 // float32 activations, 3 .. 10 rows: split into three bf16 planes stacked as 3m rows (workspace), one staged launch, the planes'
 // rows added in its reduction - where the staged kernel takes 3m rows (x in LDS, one round of workgroups)
 static bool rows_f32_planes_ok(int64_t m, int64_t n, int64_t k, const void* workspace, size_t workspace_bytes) {
@@ -183,8 +184,9 @@ bool gemm_rows_supported(const void* x, int x_dtype, int64_t m, int64_t k, int64
     if (n > INT32_MAX - 64 || k > INT32_MAX) return false;
     if (x_dtype == TVL_F32) return aligned(x, 16) && (ld_x * 4) % 16 == 0 && rows_f32_planes_ok(m, n, k, workspace, workspace_bytes);
     if (x_dtype != TVL_F16 && x_dtype != TVL_BF16) return false;
-    if (m < 3 || m > 64 || k <= 0 || k % 256 != 0) return false;
+    if (m < 3 || m > 512 || k <= 0 || k % 256 != 0) return false;
     if (!aligned(x, 16) || (ld_x * 2) % 16 != 0) return false;
+    if (m > 64) return rows_use_blocks(m, n, k);   // 65 .. 512 rows on small layers: the staged form on blocks of 64 rows
     if (m > 32) return rows_use_staged(m, n, k);   // 33 .. 64 rows: only the staged form
     const double work = (double)m * (double)n * (double)k;
     if (rows_use_staged(m, n, k)) return true;
@@ -235,7 +237,7 @@ int launch_gemm_rows(const void* x, int x_dtype, int64_t m, int64_t k, int64_t l
         if (int rc = launch_split_f32_rows((const float*)x, m, k, ld_x, xs, st); rc != TVL_OK) return rc;
         return launch_rows_staged_x((const bf16_t*)xs, 3 * m, k, k, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, 3, st);
     }
-    if (rows_use_staged(m, n, k)) {
+    if (m > 64 || rows_use_staged(m, n, k)) {   // (more than 64 rows: gemm_rows_supported admitted them for the row-block form)
         if (x_dtype == TVL_F16) return launch_rows_staged_x((const f16*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, 1, st);
         return launch_rows_staged_x((const bf16_t*)x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, 1, st);
     }
@@ -253,7 +255,7 @@ static size_t rows_staged_lds_bytes(int mr, int ct, int64_t k) {
 // 16-channel tiles per workgroup: 1 while one round of workgroups covers n, else 2, 4 or 8 (two phases at 17 .. 32 rows: 1; 33 .. 64 rows: 2 or 4,
 // the waves splitting them)
 static int rows_staged_tiles(int64_t m, int64_t n, int64_t k) {
-    if (m > 32) return ceil_div(n, 32) <= (int64_t)device_cu_count() ? 2 : 4;
+    if (m > 32) return ceil_div(n, 32) * ceil_div(m, 64) <= (int64_t)device_cu_count() ? 2 : 4;
     const int mr = m <= 16 ? 1 : 2;
     if (mr == 2 && k > 2048) return 1;
     // (measured beyond these: 16 x 16384 x 8192 with 4 tiles 17.4 -> 17.8 us, 16 x 28672 x 4096 with 8 tiles 14.5 -> 16.6: not used)
@@ -292,6 +294,12 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
     const int sw = wave % SW, tg = wave / SW;                         // this wave's step slot inside a phase and its tile group
     const int c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * (16 * CT);
+    if (gridDim.y > 1) {   // 65 .. 512 rows: blockIdx.y selects a block of 16 MR rows, a product of its own on the same weights
+        const int r0 = (int)blockIdx.y * (16 * MR);
+        x += (int64_t)r0 * ld_x;
+        y = reinterpret_cast<unsigned char*>(y) + (int64_t)r0 * ld_y * (y_dtype == TVL_F32 ? 4 : 2);
+        m = m - r0 < 16 * MR ? m - r0 : 16 * MR;
+    }
     const int total = k / 256;
     const int nph = (total + PS - 1) / PS;                            // phases this k needs (<= PH)
 
@@ -432,7 +440,8 @@ static int launch_rows_staged_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_
     const size_t lds_bytes = rows_staged_lds_bytes(MR, CT, k);
     auto kern = gemm_rows_staged_kernel<TX, MR, CT, SPW, PH, TW>;
     if (int rc = set_dynamic_lds_limit((const void*)kern, lds_bytes); rc != TVL_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(n, 16 * CT)), dim3(512), lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip,
+    const unsigned row_blocks = m > 64 ? (unsigned)ceil_div(m, 16 * MR) : 1u;   // (only the 64-row form is launched with more than 64 rows)
+    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(n, 16 * CT), row_blocks), dim3(512), lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip,
                        act, act_begin, y, y_dtype, ld_y, planes);
     TVL_LAUNCH_CHECK();
     return TVL_OK;
@@ -446,7 +455,7 @@ static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x,
 #define TVL_STAGED_TW(MR, CT, PH) \
     return launch_rows_staged_cfg<TX, MR, CT, 1, PH, 2>(x, m, k, ld_x, pw, n, ld_pw, scale, bias, clip, act, act_begin, y, y_dtype, ld_y, planes, st)
         if (k <= 2048) {
-            if (m <= 48) { if (ct == 2) TVL_STAGED_TW(3, 2, 2); TVL_STAGED_TW(3, 4, 2); }
+            if (m <= 48) { if (ct == 2) TVL_STAGED_TW(3, 2, 2); TVL_STAGED_TW(3, 4, 2); }   // (more than 64 rows: blocks of 64 over blockIdx.y)
             if (ct == 2) TVL_STAGED_TW(4, 2, 2);
             TVL_STAGED_TW(4, 4, 2);
         }
@@ -489,6 +498,21 @@ static int launch_rows_staged_x(const TX* x, int64_t m, int64_t k, int64_t ld_x,
 // 3 .. 5 rows on up to 2048 channels with k > 4096: the plain kernel (four waves split k, x from global memory) beats both LDS-staged forms, whose
 // staging of a long k is not repaid by so few rows and workgroups (3 x 2048 x 8192: 8.3 -> 7.4 us, 5 x 2048 x 6144: 8.1 -> 6.8)
 static bool rows_few_long_k(int64_t m, int64_t n, int64_t k) { return m <= 5 && n <= 2048 && k > 4096; }
+// 65 .. 512 rows, k <= 2048, few channels (the batch-256 out_proj of a Phi block, 256 x 2048 x 2048): too little work per output tile for
+// the matrix-core tiles, which split k and add the slabs in a second launch.  The staged kernel takes blocks of 64 rows over
+// blockIdx.y instead (x of a block = 256 KiB in two LDS phases, weights re-read from L2 by each row block), one launch, while one
+// round of workgroups covers the output.  Measured (us, tiles -> row blocks): 256 x 2048^2 13.3 -> 9.4, 128 x 2048^2 11.2 -> 8.9,
+// 256 x 4096 x 2048 14.8 -> 12.1, 512 x 2048^2 14.8 -> 12.5, 256 x 1024^2 9.0 -> 6.3, 320 x 1536 x 2048 13.3 -> 9.4.
+// TVL_ROWS_BLOCKS=0 turns it off, 2 lifts the size rule (tuning, tests).
+static bool rows_use_blocks(int64_t m, int64_t n, int64_t k) {
+    static const int mode = [] { const char* e = getenv("TVL_ROWS_BLOCKS"); return e ? atoi(e) : 1; }();
+    if (mode == 0 || m <= 64 || m > 512 || k > 2048 || n < 32) return false;
+    const int64_t rb = ceil_div(m, 64), cus = device_cu_count();
+    if (ceil_div(n, 64) * rb > cus) return false;          // one round of workgroups, one per compute unit (133 KiB of LDS)
+    if (mode == 2) return true;
+    return k >= 1024 && (double)n * (double)k >= 5.0e5;   // (k = 512: 448 x 2048 x 512 6.9 -> 8.0 us, the tiles win)
+}
+
 static bool rows_use_staged(int64_t m, int64_t n, int64_t k) {
     static const int mode = [] { const char* e = getenv("TVL_ROWS_STAGED"); return e ? atoi(e) : 1; }();   // 2: whatever fits (tests)
     if (m > 64 || k > (m <= 16 ? 8192 : 4096)) return false;   // (17 .. 32 rows in four phases up to k = 8192: built, 12.4 - 13.9 us against 9.0 - 13.1 without)

@@ -205,6 +205,22 @@ def test_staged_rows_kernel_on_small_shapes():
     assert out.stdout.count(": ok") == 6 * len(shapes)
 
 
+def test_staged_rows_kernel_on_blocks_of_64_rows():
+    """65 .. 512 rows on small layers run the staged few-row kernel on blocks of 64 rows (blockIdx.y); a child process lifts the size
+    rule (TVL_ROWS_BLOCKS=2) so that ragged shapes reach it: a last block of 1 .. 64 rows, channel counts that are not multiples
+    of 32, one and two staging phases, two and four channel tiles per workgroup, every dtype pair, against the CPU oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = ["65,96,512", "100,300,1024", "128,130,2048", "129,257,1280", "200,2048,2048", "256,33,256", "300,500,768", "512,64,2048",
+              "449,2000,1024", "256,4000,256"]
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_plan.py"), *shapes],
+                         env=dict(os.environ, TVL_ROWS_BLOCKS="2", CHECK_EXTRA="0,16,32"), capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert out.stdout.count(": ok") == 6 * len(shapes)
+
+
 def test_table_lookup_kernel_geometries_on_one_to_four_rows():
     """The one-to-four-row table-lookup kernel in each launch geometry: waves that own channels (short k, many channels), and
     blocks whose four waves split k over two (one row, up to 2048 channels) or four shared channels (k >= 4096, up to 6144
