@@ -506,10 +506,13 @@ static bool rows_few_long_k(int64_t m, int64_t n, int64_t k) { return m <= 5 && 
 // TVL_ROWS_BLOCKS=0 turns it off, 2 lifts the size rule (tuning, tests).
 static bool rows_use_blocks(int64_t m, int64_t n, int64_t k) {
     static const int mode = [] { const char* e = getenv("TVL_ROWS_BLOCKS"); return e ? atoi(e) : 1; }();
-    if (mode == 0 || m <= 64 || m > 512 || k > 2048 || n < 32) return false;
+    if (mode == 0 || m <= 64 || m > 512 || k > 4096 || n < 32) return false;
     const int64_t rb = ceil_div(m, 64), cus = device_cu_count();
     if (ceil_div(n, 64) * rb > cus) return false;          // one round of workgroups, one per compute unit (133 KiB of LDS)
-    if (mode == 2) return true;
+    if (mode >= 2) return true;
+    // four staging phases (k > 2048) are bound by every workgroup's pass over its rows of x through L2: they pay where the output is large
+    // (256 x 3072^2 17.7 -> 15.8 us, 512 x 2048 x 4096 22.7 -> 20.2, 128 x 8192 x 4096 23.2 -> 20.1; 128 x 4096^2 15.9 -> 16.4, 96 x 4096^2 14.3 -> 15.6)
+    if (k > 2048) return (double)m * (double)n >= 7.5e5;
     return k >= 1024 && (double)n * (double)k >= 5.0e5;   // (k = 512: 448 x 2048 x 512 6.9 -> 8.0 us, the tiles win)
 }
 
