@@ -149,9 +149,11 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
             /* 1 x 8 waves; the 2 x 4 layout (WAVES_M = 2: half the LDS reads, twice the weight decode) measured 21 % slower */ \
             const int cus = device_cu_count();                                                                      \
             const bool persist = nblk > cus;   /* more tiles than CUs: one workgroup per CU walks several (+2..7 %) */ \
-            /* the persistent form has no registers left for the fourth weight set (it would spill): three tiles there */ \
-            auto k16 = persist ? gemm_mfma16_kernel<TX, TY, HB, ACT, 1, true, NBUF> : gemm_mfma16_kernel<TX, TY, HB, ACT, 1, false, BIG_NB>; \
-            const size_t lds16 = (size_t)(persist ? NBUF : BIG_NB) * BM * ROW_BYTES;                                \
+            /* the persistent form runs its steps in eight phases of four row tiles (PARTS = 4: 32 fewer fragment registers), which */ \
+            /* leaves room for the fourth weight register set: tiles two steps ahead there too (ViT-Base fc1 137 -> 130 us, qkv 102 -> 99) */ \
+            auto k16 = persist ? gemm_mfma16_kernel<TX, TY, HB, ACT, 1, true, BIG_NB, 256, 8, false, 2, 32, 4>      \
+                               : gemm_mfma16_kernel<TX, TY, HB, ACT, 1, false, BIG_NB>;                             \
+            const size_t lds16 = (size_t)BIG_NB * BM * ROW_BYTES;                                                   \
             if (int rc = set_dynamic_lds_limit((const void*)k16, lds16); rc != TVL_OK) return rc;                   \
             hipLaunchKernelGGL(k16, dim3(persist ? cus : nblk), block, lds16, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, \
                                bias, clip, act_begin, y, ld_y, tiles_n, nblk, w_steps, 0);                         \

@@ -434,7 +434,7 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     constexpr int MT = WM / 16, NTL = WN / 16;            // 16 x 16 tiles per wave: 16 x 2 or 8 x 4
     constexpr int MH = MT / 2, NH = NTL / 2;              // per phase: MH row tiles x NTL channel tiles, NH decodes
     constexpr int MP = MT / PARTS;                        // PARTS != 2: phases of MP row tiles (fewer fragment registers: more waves per SIMD)
-    static_assert(MT % PARTS == 0 && (PARTS == 2 || (PARTS % NTL == 0 && !PERSIST)), "phase split");
+    static_assert(MT % PARTS == 0 && (PARTS == 2 || PARTS % NTL == 0), "phase split");
     constexpr int A_TILE_BYTES = BM * ROW_BYTES;
     constexpr int ROUNDS = (BM * 8) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NB * A_TILE_BYTES
@@ -700,8 +700,7 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
             phase_g(std::integral_constant<int, 5>{}, buf_c, w0, w1, wn);
             phase_g(std::integral_constant<int, 6>{}, buf_c, w0, w1, wn);
             phase_g(std::integral_constant<int, 7>{}, buf_c, w0, w1, wn);
-            return;
-        }
+        } else {
         read_a(buf, 0, 1, afB);
         __builtin_amdgcn_sched_barrier(0);
         decode_part(w0, 1, 0, bf1); mma(afA, 0, bf0);
@@ -727,8 +726,9 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         decode_part(w1, 0, 1, bf0); mma(afB, 1, bf1);
         interleave_hint();
         __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (PERSIST) {
-            if (++kb_c == nk) {   // last step of a tile: write it out and start the next one (its first fragments are in afA / bf0)
+            if (++kb_c == nk) {   // last step of a tile: write it out and start the next one (its first fragments are in afA / afG0 and bf0)
                 store_tile();
 #pragma unroll
                 for (int i = 0; i < MT; ++i)

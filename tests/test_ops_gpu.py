@@ -749,7 +749,8 @@ def test_matmul_route_names_the_kernels(ops):
     assert "256x256" in r(torch.float16, 4096, 4096, 4096)
     assert "gemv_kernel" in r(torch.float16, 1, 4096, 4096)
     assert "gemm_rows" in r(torch.float16, 16, 4096, 4096)
-    assert "split-k" in r(torch.float16, 256, 4096, 4096) and "splitk_reduce_kernel" in r(torch.float16, 256, 4096, 4096)
+    assert "split-k" in r(torch.float16, 256, 2048, 8192) and "splitk_reduce_kernel" in r(torch.float16, 256, 2048, 8192)
+    assert "gemm_rows_staged_kernel" in r(torch.float16, 256, 2048, 2048)          # blocks of 64 rows on a small layer
     assert "split_f32_kernel" in r(torch.float32, 4096, 4096, 4096)
     assert "pad_rows_kernel" in r(torch.float16, 729, 1152, 4304)
     assert r(torch.float16, 3, 7, 5) == "gemm_generic_kernel"
