@@ -324,14 +324,23 @@ gemm_rows_staged_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, co
             }
     };
     const int st_dst = (st_p & 7) * FS + (st_p >> 3) * 16 + st_row;
-    // the LDS image holds min(total, PS) steps (rows_staged_lds_bytes): steps past the end of k are loaded (clamped) but never stored
+    // The LDS image holds min(total, PS) steps (rows_staged_lds_bytes).  With a whole phase in LDS (total >= PS) every slot exists and
+    // the stores are unconditional (steps past the end of k hold the last step again and are never read); with fewer steps than a
+    // phase the slots past the end do not exist and their stores are skipped.
     auto store_phase = [&](int ph) __attribute__((always_inline)) {
+        if (total >= PS) {
 #pragma unroll
-        for (int s = 0; s < PS; ++s)
-            if (ph * PS + s < total) {
+            for (int s = 0; s < PS; ++s)
 #pragma unroll
                 for (int i = 0; i < MR; ++i) *reinterpret_cast<nts_u32x4*>(xbuf + (s * MR + i) * IMG + st_dst) = st[s][i];
-            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < PS; ++s)
+                if (ph * PS + s < total) {
+#pragma unroll
+                    for (int i = 0; i < MR; ++i) *reinterpret_cast<nts_u32x4*>(xbuf + (s * MR + i) * IMG + st_dst) = st[s][i];
+                }
+        }
     };
     load_phase(0);
     // ---- weight loads of all of this wave's steps: step ph * PS + sw * SPW + q (past the end: the last step again, never used)
