@@ -84,15 +84,17 @@ __global__ void __launch_bounds__(64 * (MW + IW)) mfma_rate_kernel(int steps, un
 // L2-resident buffer into the tile that was read two steps ago (counted wait, as in the kernel).
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-template <int ADD, bool WIDE = false>
-__global__ void __launch_bounds__(512, 2) step_study_kernel(int steps, const uint4* __restrict__ src, unsigned long long* __restrict__ out, float* __restrict__ sink) {
+template <int ADD, bool WIDE = false, int SCHED = 0, bool FAT = false>
+__global__ void __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) step_study_kernel(int steps, const uint4* __restrict__ src, unsigned long long* __restrict__ out, float* __restrict__ sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 4 tiles of 32 KiB
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 15, g = lane >> 4, q = (0x2130 >> (4 * g)) & 3, sw = (c >> 1) & 7;
     uint32_t wreg[4] = {0x1A2B4C90u ^ (lane * 0x01010101u), 0x24681248u + lane, 0x12489A60u ^ lane, 0x0A185264u + 3 * lane};
-    constexpr int RT = WIDE ? 4 : 8, CTL = WIDE ? 4 : 2;   // row tiles per phase, channel tiles per wave
+    static_assert(!(WIDE && FAT), "one layout at a time");
+    constexpr int RT = WIDE ? 4 : 8, CTL = (WIDE || FAT) ? 4 : 2;   // row tiles per phase, channel tiles per wave (FAT: 4 waves x (256 rows x 64 channels))
+    constexpr int NTH = FAT ? 256 : 512, PIECES = FAT ? 8 : 4;
     half8 bfrag[2][CTL];   // [MFMA group s][channel tile]
-    for (int i = tid; i < 4 * 32768 / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = src[i & 4095];
+    for (int i = tid; i < 4 * 32768 / 16; i += NTH) reinterpret_cast<uint4*>(lds)[i] = src[i & 4095];
     __syncthreads();
     floatx4 acc[2 * RT][CTL];
 #pragma unroll
@@ -142,16 +144,16 @@ __global__ void __launch_bounds__(512, 2) step_study_kernel(int steps, const uin
             for (int t = 0; t < CTL; ++t) acc[RT * half + i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfrag[s][t], af[i], acc[RT * half + i][t], 0, 0, 0);
     };
     auto decode_phase = [&](int s, int ph) __attribute__((always_inline)) {   // the decodes of one phase: one fragment (narrow) or two (wide)
-        if constexpr (WIDE) { decode(s, 2 * ph); decode(s, 2 * ph + 1); } else decode(s, ph);
+        if constexpr (WIDE || FAT) { decode(s, 2 * ph); decode(s, 2 * ph + 1); } else decode(s, ph);
     };
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
     const uint32_t goff = (uint32_t)(tid * 16);
     auto stage = [&](int buf) __attribute__((always_inline)) {
         if constexpr (ADD & 4) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + buf * 32768 + (i * 512 + wid * 64) * 16);
-                const uint4* sbase = src + i * 512;
+            for (int i = 0; i < PIECES; ++i) {
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + buf * 32768 + (i * NTH + wid * 64) * 16);
+                const uint4* sbase = src + i * NTH;
                 uint32_t keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(goff), "s"(dst), "s"(sbase) : "memory");
@@ -163,25 +165,43 @@ __global__ void __launch_bounds__(512, 2) step_study_kernel(int steps, const uin
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int st = 0; st < steps; ++st) {
         const int buf = st & 3, buf1 = (st + 1) & 3;
+        // SCHED 0: a phase's fragment reads first (pinned), then its 16 matrix instructions with the decode among them (the kernels' form);
+        // SCHED 1: reads, decode and matrix instructions of a phase interleaved by the scheduler hint: 1 read, 2 matrix instructions, some vector work
+        auto pin = [&]() __attribute__((always_inline)) { if constexpr (SCHED == 0) __builtin_amdgcn_sched_barrier(0); };
+        auto hint = [&]() __attribute__((always_inline)) {
+            if constexpr (SCHED == 1) {
+                constexpr int GROUPS = WIDE ? 4 : 8, MF = RT * CTL / GROUPS, VA = (ADD & 2) ? (WIDE ? 10 : (FAT ? 5 : 3)) : 0, DS = (ADD & 1) ? 1 : 0;
+#pragma unroll
+                for (int j = 0; j < GROUPS; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);   // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);   // matrix instructions
+                    __builtin_amdgcn_sched_group_barrier(0x002, VA, 0);   // decode VALU
+                }
+            }
+        };
         read_a(buf, 0, 1, afB);
-        __builtin_amdgcn_sched_barrier(0);
+        pin();
         decode_phase(1, 0); mma(afA, 0, 0);
+        hint();
         __builtin_amdgcn_sched_barrier(0);
         read_a(buf, 1, 0, afA);
-        __builtin_amdgcn_sched_barrier(0);
+        pin();
         decode_phase(1, 1); mma(afB, 1, 0);
+        hint();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ADD & 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (ADD & 4) { if constexpr (FAT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();
         read_a(buf, 1, 1, afB);
         stage((st + 3) & 3);
         wreg[0] = wreg[0] * 1664525u + 1013904223u; wreg[1] ^= wreg[0] >> 3; wreg[2] += wreg[1]; wreg[3] ^= wreg[2] << 1;
-        __builtin_amdgcn_sched_barrier(0);
+        pin();
         decode_phase(0, 0); mma(afA, 0, 1);
+        hint();
         __builtin_amdgcn_sched_barrier(0);
         read_a(buf1, 0, 0, afA);
-        __builtin_amdgcn_sched_barrier(0);
+        pin();
         decode_phase(0, 1); mma(afB, 1, 1);
+        hint();
         __builtin_amdgcn_sched_barrier(0);
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -195,15 +215,16 @@ __global__ void __launch_bounds__(512, 2) step_study_kernel(int steps, const uin
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
 }
 
-template <int ADD, bool WIDE = false>
+template <int ADD, bool WIDE = false, int SCHED = 0, bool FAT = false>
 static void run_study(const char* name, const uint4* src, unsigned long long* d_out, float* sink) {
     const int steps = 8000, wgs = 256;
-    auto kern = step_study_kernel<ADD, WIDE>;
+    auto kern = step_study_kernel<ADD, WIDE, SCHED, FAT>;
+    const int nth = FAT ? 256 : 512, wv = FAT ? 4 : 8, per_wave = FAT ? 128 : 64;
     CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), 4 * 32768, 0, steps, src, d_out, sink);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(nth), 4 * 32768, 0, steps, src, d_out, sink);
     CHECK(hipEventRecord(e0, 0));
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), 4 * 32768, 0, steps, src, d_out, sink);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(kern, dim3(wgs), dim3(nth), 4 * 32768, 0, steps, src, d_out, sink);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipDeviceSynchronize());
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -211,7 +232,7 @@ static void run_study(const char* name, const uint4* src, unsigned long long* d_
     std::vector<unsigned long long> h(wgs);
     CHECK(hipMemcpy(h.data(), d_out, wgs * 8, hipMemcpyDeviceToHost));
     std::sort(h.begin(), h.end());
-    printf("%-86s %6.3f us per step  %7.1f TFLOP/s  %6.0f cycles per step (%.2f GHz)\n", name, us_per_step, 256.0 * 8 * 64 * 16384.0 / (us_per_step * 1e-6) / 1e12,
+    printf("%-86s %6.3f us per step  %7.1f TFLOP/s  %6.0f cycles per step (%.2f GHz)\n", name, us_per_step, 256.0 * wv * per_wave * 16384.0 / (us_per_step * 1e-6) / 1e12,
            (double)h[wgs / 2] / steps, (double)h[wgs / 2] / steps / us_per_step * 1e-3);
 }
 
@@ -263,5 +284,17 @@ int main() {
     run_study<1, true>("+ activation fragments from LDS (16 ds_read_b128 per wave and step)", src, d_out, sink);
     run_study<3, true>("+ LDS fragments + decode (80 vector instructions per wave and step)", src, d_out, sink);
     run_study<7, true>("+ LDS fragments + decode + LDS-DMA", src, d_out, sink);
+    printf("--- fragment reads, decode and matrix instructions of a phase interleaved by sched_group_barrier instead of reads first\n");
+    run_study<1, false, 1>("+ LDS fragments", src, d_out, sink);
+    run_study<3, false, 1>("+ LDS fragments + decode", src, d_out, sink);
+    run_study<7, false, 1>("+ LDS fragments + decode + LDS-DMA", src, d_out, sink);
+    run_study<7, true, 1>("128 x 64 waves: + LDS fragments + decode + LDS-DMA", src, d_out, sink);
+    printf("--- four waves of 256 rows x 64 channels (one per SIMD, 256 accumulator registers: half the fragment reads, the same decode)\n");
+    run_study<0, false, 0, true>("matrix instructions + barrier only", src, d_out, sink);
+    run_study<1, false, 0, true>("+ LDS fragments (32 per wave and step), reads first", src, d_out, sink);
+    run_study<7, false, 0, true>("+ LDS fragments + decode + LDS-DMA, reads first", src, d_out, sink);
+    run_study<1, false, 1, true>("+ LDS fragments, interleaved", src, d_out, sink);
+    run_study<3, false, 1, true>("+ LDS fragments + decode, interleaved", src, d_out, sink);
+    run_study<7, false, 1, true>("+ LDS fragments + decode + LDS-DMA, interleaved", src, d_out, sink);
     return 0;
 }
