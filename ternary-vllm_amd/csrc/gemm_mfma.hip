@@ -153,7 +153,7 @@ static int launch_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const uin
             /* leaves room for the fourth weight register set: tiles two steps ahead there too (ViT-Base fc1 137 -> 130 us, qkv 102 -> 99) */ \
             auto k16 = persist ? gemm_mfma16_kernel<TX, TY, HB, ACT, 1, true, BIG_NB, 256, 8, false, 2, 32, 4>      \
                                : gemm_mfma16_kernel<TX, TY, HB, ACT, 1, false, BIG_NB>;                             \
-            const size_t lds16 = (size_t)BIG_NB * BM * ROW_BYTES;                                                   \
+            const size_t lds16 = (size_t)BIG_NB * BM * ROW_BYTES + (persist ? persist_param_lds_bytes(8) : 0);      \
             if (int rc = set_dynamic_lds_limit((const void*)k16, lds16); rc != TVL_OK) return rc;                   \
             hipLaunchKernelGGL(k16, dim3(persist ? cus : nblk), block, lds16, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, \
                                bias, clip, act_begin, y, ld_y, tiles_n, nblk, w_steps, 0);                         \

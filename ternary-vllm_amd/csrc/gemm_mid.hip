@@ -72,8 +72,9 @@ static int launch_mid_cfg(const TX* x, int64_t m, int64_t k, int64_t ld_x, const
         if constexpr (WAVES == 8) {                                                                                         \
             if (persist) {                                                                                                  \
                 auto kp = gemm_mfma16_kernel<TX, TY, HB, ACT, 1, true, MID_NB, BM, WAVES, false, 2>;                        \
-                if ((rc = set_dynamic_lds_limit((const void*)kp, lds_bytes)) != TVL_OK) return rc;                          \
-                hipLaunchKernelGGL(kp, dim3(cus), block, lds_bytes, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, \
+                const size_t lds_p = lds_bytes + persist_param_lds_bytes(WAVES);   /* + the staged scale / bias */           \
+                if ((rc = set_dynamic_lds_limit((const void*)kp, lds_p)) != TVL_OK) return rc;                              \
+                hipLaunchKernelGGL(kp, dim3(cus), block, lds_p, st, x, (int)m, (int)k, ld_x, pw, (int)n, ld_pw, scale, bias, clip, \
                                    act_begin, y, ld_y, tiles_n, nblk, w_steps, 0);                                          \
                 break;                                                                                                      \
             }                                                                                                               \

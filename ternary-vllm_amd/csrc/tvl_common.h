@@ -96,6 +96,15 @@ __device__ __forceinline__ float gelu_tanh_f32(float x) {
     return x * (1.0f - r);   // (not x - x r: +inf must stay +inf)
 }
 
+// the first two steps of the epilogue alone (for callers that clip after their own rounding)
+template <bool HAS_BIAS>
+__device__ __forceinline__ float scale_bias(float acc, float scale, float bias) {
+#pragma clang fp contract(off)
+    float y = acc * scale;
+    if constexpr (HAS_BIAS) y = y + bias;
+    return y;
+}
+
 template <bool HAS_BIAS, int ACT>
 __device__ __forceinline__ float epilogue(float acc, float scale, float bias, float clip) {
     // the reference does `x *= scale; x += bias` as two float32 operations: keep the compiler from

@@ -100,6 +100,47 @@ def test_headline_4096_full_output_and_randn_rows(ops, dev, c_oracle):
     assert rel_gpu <= max(2.0 * rel_cpu, 2.0 ** -22)
 
 
+@pytest.mark.parametrize("k,form", [(1024, "256x256"), (768, "256x256 persistent"), (128, "256x256 persistent")])
+def test_full_tile_epilogue_clips_after_rounding_like_before_it(ops, dev, c_oracle, k, form):
+    """Tiles inside the output take a shorter epilogue on the 256 x 256 kernel: float16 results are clipped on the packed halves
+    after the conversion, scale and bias come as vectors (from LDS in the persistent form).  With a clip that binds on most
+    outputs, a clip beyond the float16 range, channels whose bias is +-inf or NaN and scales that overflow float32, every
+    16-bit output must still be the one rounding of the C restatement's float32 value."""
+    for m, n in ((4096, 4096), (16384, 4096), (25216, 3072), (32768, 4096)):     # the first shape the planner gives this form of the kernel
+        route = ops.matmul_route(torch.float16, m, n, k)
+        if route.startswith("gemm_mfma16_kernel " + form) and ("persistent" in route) == ("persistent" in form):
+            break
+    else:
+        pytest.fail(f"no candidate shape runs as {form} at k = {k}: last route {route}")
+    x, w, scale, bias = _problem(m + k, m, n, k)
+    scale[5::64] *= 64.0
+    scale[7] = 3e38                                        # acc * scale overflows to +-inf before the clip
+    bias[3], bias[258], bias[n - 1] = np.inf, -np.inf, np.nan
+    want_pw = O.pack_format_c(O.ternarize(w))
+    pw = torch.from_numpy(want_pw).to(dev)
+    st, bt = torch.from_numpy(scale).to(dev), torch.from_numpy(bias).to(dev)
+    xh = torch.from_numpy(x).to(dev).half()
+    for clip in (3.0, 70000.0, 1e30):
+        with np.errstate(over="ignore", invalid="ignore"):
+            want = c_oracle(x, want_pw, scale, bias, clip)
+            want_nb = c_oracle(x, want_pw, scale, None, clip)
+        assert np.isnan(want[:, n - 1]).all() and np.all(want[:, 3] == clip) and np.all(want[:, 258] == -clip)
+        if clip == 3.0:
+            assert (np.abs(want[:, 5::64]) == 3.0).mean() > 0.5    # the clip binds
+        for odt in (torch.float16, torch.bfloat16):
+            got = ops.ternary_matmul(xh, pw, st, bt, clip, out_dtype=odt).float().cpu().numpy()
+            assert np.array_equal(got, torch.from_numpy(want).to(odt).float().numpy(), equal_nan=True), (clip, odt)
+            got = ops.ternary_matmul(xh, pw, st, None, clip, out_dtype=odt).float().cpu().numpy()
+            assert np.array_equal(got, torch.from_numpy(want_nb).to(odt).float().numpy(), equal_nan=True), (clip, odt, "no bias")
+    # the activation variant keeps the float32 clip in front of the GELU
+    with np.errstate(over="ignore", invalid="ignore"):
+        lin = c_oracle(x[:512], want_pw, scale, bias, 3.0)
+    got = ops.ternary_matmul(xh, pw, st, bt, 3.0, activation="gelu_tanh", out_dtype=torch.float16)[:512].float().cpu().numpy()
+    want_act = torch.from_numpy(O.gelu_tanh(lin).astype(np.float32)).half().float().numpy()
+    ok = np.isfinite(want_act)
+    assert np.array_equal(np.isnan(got), np.isnan(want_act)) and np.max(np.abs(got[ok] - want_act[ok])) <= 2e-3
+
+
 def test_rows_beyond_whole_rounds_of_big_tiles_go_to_a_second_launch(ops, dev, c_oracle):
     """4500 x 4096 x 4096: 288 tiles of 256 x 256 on 256 compute units.  The library gives the 4096 rows that fill one round to
     the big tile and the other 404 rows to smaller tiles in a second launch; every output against the C restatement."""

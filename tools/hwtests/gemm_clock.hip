@@ -2,7 +2,7 @@
 // shader-clock (s_memtime) and 100 MHz (s_memrealtime) stamps at entry, around the k loop and after the epilogue, runs back-to-back
 // launches on random data for ~2 s and prints, as medians over workgroups of the LAST launch: the clock held over the k loop,
 // cycles and microseconds of prologue / loop / epilogue, cycles per 64-deep k step.
-//   usage: gemm_clock [form=0|1|2] [M N K [splits [lds_tiles]]]   (0: the shipped 256 x 256 tile, 1: four waves x 64 channels, 2: 128 x 128 split-K)
+//   usage: gemm_clock [form=0|1|2] [M N K [splits [lds_tiles]]]   (0: the shipped 256 x 256 tile, 1: four waves x 64 channels, 2: 128 x 128 split-K, 3: the persistent 256 x 256 form, 4: the same with three LDS tiles and four phases, 5: form 0 in eight phases)
 #define TVL_CLOCK_PROBE 1
 #include "../../ternary-vllm_amd/csrc/gemm_mfma_kernels.h"
 
@@ -21,7 +21,7 @@ static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return
 template <int NB>
 static void run_mid_split(int m, int n, int k, int splits, const f16* x, const uint8_t* pw, const float* sc, const float* bi, float* slab) {
     auto kern = gemm_mfma16_kernel<f16, float, false, TVL_ACT_NONE, 1, false, NB, 128, 4, true, 3>;
-    const size_t lds = (size_t)NB * 128 * ROW_BYTES;
+    const size_t lds = (size_t)NB * 128 * ROW_BYTES + 2048;   // + the step stamps
     CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tiles_n = (n + 127) / 128, nblk = ((m + 127) / 128) * tiles_n, per = (k / 64 + splits - 1) / splits;
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -51,11 +51,11 @@ static void run_mid_split(int m, int n, int k, int splits, const f16* x, const u
     printf("  first workgroup entry to last workgroup exit (k range 0 only): %.2f us\n", (r_last - r_first) * 0.01);
 }
 
-template <int WAVES, int WN, int MINW>
+template <int WAVES, int WN, int MINW, int PARTS = 2>
 static void run(int m, int n, int k, const f16* x, const uint8_t* pw, const float* sc, const float* bi, f16* y) {
     constexpr int NB = 4;
-    auto kern = gemm_mfma16_kernel<f16, f16, true, TVL_ACT_NONE, 1, false, NB, 256, WAVES, false, MINW, WN>;
-    const size_t lds = (size_t)NB * 256 * ROW_BYTES;
+    auto kern = gemm_mfma16_kernel<f16, f16, true, TVL_ACT_NONE, 1, false, NB, 256, WAVES, false, MINW, WN, PARTS>;
+    const size_t lds = (size_t)NB * 256 * ROW_BYTES + 2048;   // + the step stamps
     CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tiles_n = (n + 255) / 256, nblk = ((m + 255) / 256) * tiles_n;
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -89,6 +89,47 @@ static void run(int m, int n, int k, const f16* x, const uint8_t* pw, const floa
     printf("  first workgroup entry to last workgroup exit: %.2f us\n", (r_last - r_first) * 0.01);
 }
 
+// the persistent form (one workgroup per CU walks its tiles as one stream of k steps): per-launch time and the shader clocks wave 0
+// spends in a tile switch (epilogue arithmetic, store issue, zeroing the accumulators, the next tile's origin)
+template <int NB, int PARTS>
+static void run_persistent(int m, int n, int k, const f16* x, const uint8_t* pw, const float* sc, const float* bi, f16* y) {
+    auto kern = gemm_mfma16_kernel<f16, f16, true, TVL_ACT_NONE, 1, true, NB, 256, 8, false, 2, 32, PARTS>;
+    const size_t lds = (size_t)NB * 256 * ROW_BYTES + persist_param_lds_bytes(8) + 2048;   // + the step stamps
+    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int tiles_n = (n + 255) / 256, nblk = ((m + 255) / 256) * tiles_n;
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    float ms = 0;
+    const int per = 500;
+    for (int round = 0; round < 8; ++round) {
+        CHECK(hipEventRecord(a, 0));
+        for (int i = 0; i < per; ++i)
+            hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, x, m, k, (int64_t)k, pw, n, (int64_t)(k / 4), sc, bi, 100.0f, 0, y, (int64_t)n,
+                               tiles_n, nblk, k / 64, 0);
+        CHECK(hipEventRecord(b, 0)); CHECK(hipEventSynchronize(b));
+        CHECK(hipEventElapsedTime(&ms, a, b));
+    }
+    std::vector<unsigned long long> h(8 * 4096), hs(2 * 4096);
+    CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(tvl_clock_probe), h.size() * 8));
+    CHECK(hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(tvl_clock_probe_switch), hs.size() * 8));
+    std::vector<double> ghz, loop, loop_us, sw, pro_us;
+    for (int bl = 0; bl < 256; ++bl) {
+        const unsigned long long* c = &h[8 * bl]; const unsigned long long* r = c + 4;
+        ghz.push_back((double)(c[2] - c[1]) / (double)(r[2] - r[1]) * 0.1);
+        loop.push_back((double)(c[2] - c[1])); loop_us.push_back((r[2] - r[1]) * 0.01); pro_us.push_back((r[1] - r[0]) * 0.01);
+        if (hs[2 * bl + 1]) sw.push_back((double)hs[2 * bl] / (double)hs[2 * bl + 1]);
+    }
+    std::vector<unsigned long long> st(4 * 256);
+    CHECK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(tvl_clock_probe_steps), st.size() * 8));
+    printf("  shader clocks from step to step, workgroup 0 (a tile switch follows every %d-th step):", k / 64);
+    for (int i = 1; i < 256 && st[i]; ++i) printf("%s%llu", (i - 1) % (k / 64) == 0 ? " | " : " ", st[i] - st[i - 1]);
+    printf("\n");
+    const double tiles_per_wg = (double)nblk / 256, steps = k / 64;
+    printf("persistent 256 x 256 (%d LDS tiles, %d phases per step), %d tiles of %d steps on 256 workgroups: %.2f us per launch (event pair)\n", NB, 2 * PARTS, nblk, k / 64, ms / per * 1e3);
+    printf("  clock %.3f GHz   prologue %.2f us   step loop %.0f cyc / %.2f us per workgroup = %.0f cyc per tile, of which the tile switch %.0f cyc (%.2f us), so %.0f cyc per step\n",
+           med(ghz), med(pro_us), med(loop), med(loop_us), med(loop) / tiles_per_wg, med(sw), med(sw) / med(ghz) * 1e-3,
+           (med(loop) / tiles_per_wg - med(sw)) / steps);
+}
+
 int main(int argc, char** argv) {
     const int wide = argc > 1 ? atoi(argv[1]) : 0;
     const int m = argc > 4 ? atoi(argv[2]) : 4096, n = argc > 4 ? atoi(argv[3]) : 4096, k = argc > 4 ? atoi(argv[4]) : 4096;
@@ -120,6 +161,9 @@ int main(int argc, char** argv) {
         else run_mid_split<4>(m, n, k, splits, x, pw, sc, bi, slab);
         return 0;
     }
+    if (wide == 3) { run_persistent<4, 4>(m, n, k, x, pw, sc, bi, y); return 0; }
+    if (wide == 4) { run_persistent<3, 2>(m, n, k, x, pw, sc, bi, y); return 0; }
+    if (wide == 5) { run<8, 32, 2, 4>(m, n, k, x, pw, sc, bi, y); return 0; }   // the one-tile-per-workgroup form in eight phases
     if (wide) run<4, 64, 1>(m, n, k, x, pw, sc, bi, y);
     else run<8, 32, 2>(m, n, k, x, pw, sc, bi, y);
     return 0;
