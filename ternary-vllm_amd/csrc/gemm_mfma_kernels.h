@@ -615,6 +615,19 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     // halves AFTER the conversion (v_pk_minimum3_f16 / v_pk_maximum3_f16: two values per instruction).  Rounding to nearest is
     // monotone, so round(min(max(v, -c), c)) = min(max(round(v), -round(c)), round(c)) for every v including +-inf and NaN
     // (both forms propagate NaN): bit-identical to the general path below.  ~40 % fewer vector instructions per tile.
+    // PERSIST: an empty asm that uses the fragments a phase has just decoded (the half `part` of bf).  Their real users sit in a later
+    // basic block there (the step is split by the load cursor's tile switch and the loop's continuation test), and machine sinking
+    // would move the side-effect-free decode down to them, out of its phase: 20 vector instructions in a row, the matrix pipe idle.
+    auto pin_decoded = [&](int part, uint4 (&bf)[NTL]) __attribute__((always_inline)) {
+        if constexpr (PERSIST) {
+#pragma unroll
+            for (int t = 0; t < NH; ++t) {
+                uint4& f = bf[part * NH + t];
+                asm volatile("" : "+v"(f.x), "+v"(f.y), "+v"(f.z), "+v"(f.w));
+            }
+        }
+    };
+
     auto store_tile_full = [&]() __attribute__((always_inline)) {
         if constexpr (sizeof(TY) == 2 && !SPLIT) {
         const float cl = fabsf(clip);
@@ -808,11 +821,13 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         __builtin_amdgcn_sched_barrier(0);
         decode_part(w0, 1, 0, bf1); mma(afA, 0, bf0);
         interleave_hint();
+        pin_decoded(0, bf1);
         __builtin_amdgcn_sched_barrier(0);
         read_a(buf, 1, 0, afA);
         __builtin_amdgcn_sched_barrier(0);
         decode_part(w0, 1, 1, bf1); mma(afB, 1, bf0);
         interleave_hint();
+        pin_decoded(1, bf1);
         __builtin_amdgcn_sched_barrier(0);
         // ---- middle of the step: tile kb+1 (and its weights w1) complete, tile kb-1 retired ----
         wait_mid_step(w1);
@@ -822,11 +837,13 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         __builtin_amdgcn_sched_barrier(0);
         decode_part(w1, 0, 0, bf0); mma(afA, 0, bf1);
         interleave_hint();
+        pin_decoded(0, bf0);
         __builtin_amdgcn_sched_barrier(0);
         read_a(buf1, 0, 0, afA);
         __builtin_amdgcn_sched_barrier(0);
         decode_part(w1, 0, 1, bf0); mma(afB, 1, bf1);
         interleave_hint();
+        pin_decoded(1, bf0);
         __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (PERSIST) {
