@@ -88,10 +88,9 @@ template <int MODE> __device__ __forceinline__ uint32_t quantize_code(float w, f
 // epilogue of a 25216 x 3072 x 768 product spent a third of the launch there).  Absolute error <= |x| * 2e-7 against the exact form
 // (tests: <= 1e-5 against a float64 evaluation); x = +-inf and NaN behave like the exact form (exp -> inf / 0, NaN propagates).
 __device__ __forceinline__ float gelu_tanh_f32(float x) {
-    const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
-    const float k1 = 0.044715f;
-    const float inner = k0 * (x + k1 * x * x * x);
-    const float e = __builtin_amdgcn_exp2f(inner * 2.8853900817779268f);   // exp(2 u) = 2^(2 u log2(e))
+    // 2 u log2(e) = x (B + A x^2) with B = 2 log2(e) sqrt(2/pi), A = 0.044715 B: three instructions in front of the exponential
+    const float B = 2.302208198144325f, A = 0.1029432395800235f;
+    const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, A, B));   // exp(2 u) = 2^(2 u log2(e))
     const float r = __builtin_amdgcn_rcpf(e + 1.0f);
     return x * (1.0f - r);   // (not x - x r: +inf must stay +inf)
 }

@@ -1,7 +1,7 @@
 """A/B several builds of libternary_hip.so on one ternary_matmul shape in ONE process.
     python tools/ab_libs.py M N K libA.so libB.so [libC.so ...]      (TVL_AB_DTYPE=f32|f16|bf16 picks the activation type)
-The packed weights rotate over buffers totalling > 512 MiB (more than the Infinity Cache), so every launch
-streams them from HBM.  Each sample times one sweep over all buffers between two events."""
+The packed weights and the outputs rotate over buffers totalling > 512 MiB each (more than the Infinity Cache), so every launch
+streams them from / to HBM.  Each sample times one sweep over all buffers between two events."""
 import ctypes
 import os
 import sys
@@ -23,14 +23,16 @@ x = torch.randn(M, K, device=dev).to(XD[0])
 pws = [torch.randint(0, 171, (N, K // 4), dtype=torch.uint8, device=dev) for _ in range(nb)]
 scale = torch.rand(N, device=dev) + 0.5
 bias = torch.randn(N, device=dev)
-ys = [torch.empty((M, N), dtype=torch.float16, device=dev) for _ in libs]
+# outputs rotate too (more than the 256 MiB Infinity Cache in total), so stores cannot be absorbed by a cache; TVL_AB_YBUF=1 pins one buffer
+nby = int(os.environ.get("TVL_AB_YBUF", "0")) or max(2, min(64, -(-(640 << 20) // (M * N * 2))))
+ys = [[torch.empty((M, N), dtype=torch.float16, device=dev) for _ in range(nby)] for _ in libs]
 ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
 
 
 def launch(li, i):
     rc = libs[li].tvl_ternary_matmul(x.data_ptr(), XD[1], M, K, 0, pws[i % nb].data_ptr(), N, 0, scale.data_ptr(), bias.data_ptr(), 100.0, 0,
-                                     ys[li].data_ptr(), 1, 0, ws.data_ptr(), ws.numel(), stream)
+                                     ys[li][i % nby].data_ptr(), 1, 0, ws.data_ptr(), ws.numel(), stream)
     assert rc == 0
 
 
@@ -51,5 +53,5 @@ for r in range(9):
 byts = M * K * 2 + N * K // 4 + 8 * N + M * N * 2
 for li, p in enumerate(paths):
     t = sorted(times[li])
-    same = torch.equal(ys[li], ys[0])
+    same = torch.equal(ys[li][(nb - 1) % nby], ys[0][(nb - 1) % nby])
     print(f"{M}x{N}x{K} {p:28s} median {t[len(t)//2]:7.2f} us/call  min {t[0]:7.2f}  -> {byts/t[len(t)//2]/1e3:7.1f} GB/s  same_as_first={same}")

@@ -1,7 +1,7 @@
-"""Turn the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round2.sh into profiles/r02_traffic.json, stamped with the sha256 of the
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round3.sh (or profile_round2.sh) into profiles/r0N_traffic.json, stamped with the sha256 of the
 library they were measured on (bench.py reports `roofline.traffic` only when that stamp matches the library it runs).
 
-    python tools/make_traffic_json.py gpurun_out/prof_r02 profiles/r02_traffic.json
+    python tools/make_traffic_json.py gpurun_out/prof_r03 profiles/r03_traffic.json
 """
 import hashlib
 import json
@@ -41,7 +41,7 @@ names = [("gemm_rows_staged_16x4096x4096_f16", gemm_bytes(16, 4096, 4096)), ("ge
 assert len(f) == len(names) and len(w) == len(names), (f, w)
 with open(os.path.join(root, "ternary-vllm_amd", "libternary_hip.so"), "rb") as fh:
     sha = hashlib.sha256(fh.read()).hexdigest()
-doc = {"note": "HBM-side bytes per launch from rocprofv3 --pmc passes (one pass per counter; tools/profile_round2.sh): traffic = 2 x FETCH_SIZE "
+doc = {"note": "HBM-side bytes per launch from rocprofv3 --pmc passes (one pass per counter; tools/profile_round3.sh): traffic = 2 x FETCH_SIZE "
                "(gfx950 correction: the counter reports 64-byte units as 32) + WRITE_SIZE, both in KiB per dispatch, mean over the dispatches of "
                "the pass.  The split-K kernels' entries cover the main kernel only (the slab reduce is a second dispatch).",
        "library_sha256": sha,

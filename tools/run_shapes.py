@@ -19,7 +19,9 @@ for spec in sys.argv[1:]:
     scale = torch.ones(N, device=dev)
     y = torch.empty((M, N), dtype=torch.float16, device=dev)
     torch.cuda.synchronize()
+    mark = torch.zeros(1, dtype=torch.int32, device=dev)
     for i in range(reps):
+        mark.fill_(i)   # one int32 fill kernel in front of every call: tools/trace_shapes.py splits the trace into calls there
         tv.ternary_matmul(x, pws[i % nb], scale, None, 100.0, out=y)
     torch.cuda.synchronize()
     del pws

@@ -3,16 +3,22 @@
 import csv
 import sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(t in r["Kernel_Name"] for t in ("gemm_skinny", "gemm_stream", "gemv_kernel", "gemm_mfma", "gemm_generic", "gemm_rows", "splitk_reduce"))]
+OURS = ("gemm_skinny", "gemm_stream", "gemv_kernel", "gemm_mfma", "gemm_generic", "gemm_rows", "splitk_reduce", "add_rows")
+MARK = "FillFunctor<int>"   # tools/run_shapes.py launches one int32 fill in front of every call
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if MARK in r["Kernel_Name"] or any(t in r["Kernel_Name"] for t in OURS)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 reps = int(sys.argv[2])
-calls = []  # each call: list of (name, dur)
+calls = []  # each call: list of (name, dur): the product's kernel(s), then a split-K reduce if there is one
 for r in rows:
+    if MARK in r["Kernel_Name"]:
+        calls.append([])
+        continue
+    if not calls:
+        continue   # (kernels before the first marker: none in run_shapes.py)
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    if "splitk_reduce" in r["Kernel_Name"] and calls:
-        calls[-1].append(("reduce", d))
-    else:
-        calls.append([(r["Kernel_Name"].split("(")[0][:60], d)])
+    name = r["Kernel_Name"].split("(")[0]
+    calls[-1].append(("reduce" if "splitk_reduce" in name else name[:60], d))
+calls = [c for c in calls if c]
 i = 0
 for spec in sys.argv[3:]:
     m, n, k = (int(a) for a in spec.split(","))
