@@ -435,8 +435,8 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     TVL_STAMP(0);
 #endif
     constexpr int WAVES_N = WAVES / WAVES_M;
-    constexpr int BM = BM_, BN = (WAVES_M == 1 ? WN_ : 64) * WAVES_N, NT = 64 * WAVES;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile: BM x 32 (or BM / 2 x 64)
+    constexpr int BM = BM_, BN = WN_ * WAVES_N, NT = 64 * WAVES;
+    constexpr int WM = BM / WAVES_M, WN = WN_;            // wave tile: (BM / WAVES_M) rows x WN_ channels
     constexpr int MT = WM / 16, NTL = WN / 16;            // 16 x 16 tiles per wave: 16 x 2 or 8 x 4
     constexpr int MH = MT / 2, NH = NTL / 2;              // per phase: MH row tiles x NTL channel tiles, NH decodes
     constexpr int MP = MT / PARTS;                        // PARTS != 2: phases of MP row tiles (fewer fragment registers: more waves per SIMD)
