@@ -141,6 +141,31 @@ def test_full_tile_epilogue_clips_after_rounding_like_before_it(ops, dev, c_orac
     assert np.array_equal(np.isnan(got), np.isnan(want_act)) and np.max(np.abs(got[ok] - want_act[ok])) <= 2e-3
 
 
+def test_persistent_kernel_with_ragged_edges(ops, dev, c_oracle):
+    """The persistent 256 x 256 kernel on an output whose last row tile and last channel tile are partial (and whose row length
+    keeps the 16-byte alignment of the short epilogue): inner tiles take the short epilogue with scale / bias staged through LDS,
+    edge tiles the general one, in one launch; every output against the C restatement."""
+    k = 320
+    for m, n in ((16400, 4104), (20000, 3080), (25216 + 24, 3072 + 8)):
+        route = ops.matmul_route(torch.float16, m, n, k)
+        if "256x256 persistent" in route:
+            break
+    else:
+        pytest.fail(f"no candidate shape runs on the persistent kernel: last route {route}")
+    x, w, scale, bias = _problem(m + n, m, n, k)
+    want_pw = O.pack_format_c(O.ternarize(w))
+    pw = torch.from_numpy(want_pw).to(dev)
+    st, bt = torch.from_numpy(scale).to(dev), torch.from_numpy(bias).to(dev)
+    xh = torch.from_numpy(x).to(dev).half()
+    want = c_oracle(x, want_pw, scale, bias, 2.5)
+    for odt in (torch.float16, torch.bfloat16, torch.float32):
+        got = ops.ternary_matmul(xh, pw, st, bt, 2.5, out_dtype=odt).float().cpu().numpy()
+        assert np.array_equal(got, torch.from_numpy(want).to(odt).float().numpy()), odt
+    want = c_oracle(x, want_pw, scale, None, 100.0)
+    got = ops.ternary_matmul(xh, pw, st, None, 100.0).float().cpu().numpy()
+    assert np.array_equal(got, torch.from_numpy(want).half().float().numpy())
+
+
 def test_rows_beyond_whole_rounds_of_big_tiles_go_to_a_second_launch(ops, dev, c_oracle):
     """4500 x 4096 x 4096: 288 tiles of 256 x 256 on 256 compute units.  The library gives the 4096 rows that fill one round to
     the big tile and the other 404 rows to smaller tiles in a second launch; every output against the C restatement."""
