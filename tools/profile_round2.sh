@@ -1,4 +1,4 @@
-# Round-2 profiles: kernel trace + stats of the bench command, counters of the 4096^3 GEMM, of two mid-size shapes before / after
+# Profiles kept as profiles/r02_*: kernel trace + stats of the bench command, counters of the 4096^3 GEMM, of two mid-size shapes before / after
 # the 128-row tiles (the older tiles pinned with TVL_FORCE_PLAN), of the arena pack and of the few-row kernel.  Output: gpurun_out/prof_r02/
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,4 @@
-# Round-3 profiles: kernel trace + stats of the bench command, counters of the 4096^3 GEMM and of the persistent kernel on the ViT-Base
+# Profiles kept as profiles/r03_*: kernel trace + stats of the bench command, counters of the 4096^3 GEMM and of the persistent kernel on the ViT-Base
 # fc1 shape, kernel trace of the batch-256 decode shapes, traffic of the few-row / one-row / pack kernels.  Output: gpurun_out/prof_r03/
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
