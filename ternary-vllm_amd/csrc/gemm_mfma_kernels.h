@@ -445,7 +445,7 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     constexpr int ROUNDS = (BM * 8) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NB * A_TILE_BYTES (+ persist_param_lds_bytes(WAVES) for PERSIST)
     constexpr int PARAM_OFF = NB * A_TILE_BYTES;                         // PERSIST: per wave 256 B of scale + 256 B of bias of the tile being multiplied
-    constexpr int PROBE_OFF = PARAM_OFF + (PERSIST ? 512 * WAVES : 0);   // clock-probe builds: the step stamps
+    [[maybe_unused]] constexpr int PROBE_OFF = PARAM_OFF + (PERSIST ? 512 * WAVES : 0);   // clock-probe builds: the step stamps
     static_assert(NB >= 3 && NB <= 6, "three to six activation tiles in LDS");
     constexpr int AHEAD = NB - 3;   // groups of loads (one step's tile pieces + weight dwords) the mid-step wait leaves in flight
 
@@ -611,7 +611,7 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     };
 
     // The epilogue of a tile that lies wholly inside the output, 16-bit outputs, 16-byte aligned rows: no bounds tests, scale and
-    // bias as four 16-byte loads, one row pointer advanced by a constant, and for float16 without activation the clip on the packed
+    // bias as four 16-byte loads, one row pointer advanced by a constant, and for float16 channels without activation the clip on the packed
     // halves AFTER the conversion (v_pk_minimum3_f16 / v_pk_maximum3_f16: two values per instruction).  Rounding to nearest is
     // monotone, so round(min(max(v, -c), c)) = min(max(round(v), -round(c)), round(c)) for every v including +-inf and NaN
     // (both forms propagate NaN): bit-identical to the general path below.  ~40 % fewer vector instructions per tile.
@@ -633,7 +633,6 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         const float cl = fabsf(clip);
         const int nb = n0 + wc * WN;
         const int noff = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;
-        constexpr bool CLIP16 = std::is_same<TY, f16>::value && ACT == TVL_ACT_NONE;
         typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
         const half2_t c2 = {(_Float16)cl, (_Float16)cl};
     #pragma unroll
@@ -653,33 +652,48 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
             }
             unsigned char* prow = reinterpret_cast<unsigned char*>(y + (int64_t)(m0 + wr * WM + c) * ld_y + nb + 16 * tp + noff);
             const int64_t row_step = 16 * ld_y * (int64_t)sizeof(TY);
+            // MODE: the activation on none (0) / all (1) / some (2: tested per channel) of these 32 channels; wave-uniform
+            auto rows = [&](auto mode_c) __attribute__((always_inline)) {
+                constexpr int MODE = decltype(mode_c)::value;
+                constexpr bool CLIP16 = std::is_same<TY, f16>::value && MODE == 0;
     #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                uint2 pk[2];
+                for (int i = 0; i < MT; ++i) {
+                    uint2 pk[2];
     #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    TY tmp[4];
+                    for (int t = 0; t < 2; ++t) {
+                        TY tmp[4];
     #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v;
-                        if constexpr (CLIP16) v = scale_bias<HAS_BIAS>(acc[i][tp + t][e], sc[t][e], bi[t][e]);
-                        else v = epilogue_ch<HAS_BIAS, ACT>(acc[i][tp + t][e], sc[t][e], bi[t][e], cl, nb + 16 * (tp + t) + 4 * g + e, act_begin);
-                        tmp[e] = from_float<TY>(v);
+                        for (int e = 0; e < 4; ++e) {
+                            float v;
+                            if constexpr (CLIP16) v = scale_bias<HAS_BIAS>(acc[i][tp + t][e], sc[t][e], bi[t][e]);
+                            else if constexpr (MODE == 0) v = epilogue<HAS_BIAS, TVL_ACT_NONE>(acc[i][tp + t][e], sc[t][e], bi[t][e], cl);
+                            else if constexpr (MODE == 1) v = epilogue<HAS_BIAS, ACT>(acc[i][tp + t][e], sc[t][e], bi[t][e], cl);
+                            else v = epilogue_ch<HAS_BIAS, ACT>(acc[i][tp + t][e], sc[t][e], bi[t][e], cl, nb + 16 * (tp + t) + 4 * g + e, act_begin);
+                            tmp[e] = from_float<TY>(v);
+                        }
+                        pk[t] = *reinterpret_cast<const uint2*>(tmp);
+                        if constexpr (CLIP16) {
+                            pk[t].x = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_minimum(__builtin_bit_cast(half2_t, pk[t].x), c2), -c2));
+                            pk[t].y = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_minimum(__builtin_bit_cast(half2_t, pk[t].y), c2), -c2));
+                        }
                     }
-                    pk[t] = *reinterpret_cast<const uint2*>(tmp);
-                    if constexpr (CLIP16) {
-                        pk[t].x = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_minimum(__builtin_bit_cast(half2_t, pk[t].x), c2), -c2));
-                        pk[t].y = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_minimum(__builtin_bit_cast(half2_t, pk[t].y), c2), -c2));
-                    }
+                    auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+                    auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+                    const uint4 out = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                    // One tile per workgroup: streaming (non-temporal) stores, +0.5 % at 4096^3.  The persistent form writes several times
+                    // the bytes it reads (ViT-Base fc1: 155 MB out, 43 MB in); there plain stores, which leave through L2 as whole 128-byte
+                    // lines, are 1.6 - 2.3 % faster (the write counter shows 1.4 x the output's bytes for the non-temporal form), equal elsewhere.
+                    if constexpr (PERSIST) *reinterpret_cast<uint4*>(prow + i * row_step) = out;
+                    else __builtin_nontemporal_store(__builtin_bit_cast(nts_u32x4, out), reinterpret_cast<nts_u32x4*>(prow + i * row_step));
                 }
-                auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
-                auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
-                const uint4 out = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-                // One tile per workgroup: streaming (non-temporal) stores, +0.5 % at 4096^3.  The persistent form writes several times the
-                // bytes it reads (ViT-Base fc1: 155 MB out, 43 MB in); there plain stores, which leave through L2 as whole 128-byte lines,
-                // are 1.6 - 2.3 % faster (the write counter shows 1.4 x the output's bytes for the non-temporal form) and equal elsewhere.
-                if constexpr (PERSIST) *reinterpret_cast<uint4*>(prow + i * row_step) = out;
-                else __builtin_nontemporal_store(__builtin_bit_cast(nts_u32x4, out), reinterpret_cast<nts_u32x4*>(prow + i * row_step));
+            };
+            if constexpr (ACT == TVL_ACT_NONE) {
+                rows(std::integral_constant<int, 0>{});
+            } else {
+                const int ch0 = __builtin_amdgcn_readfirstlane(nb + 16 * tp);
+                if (ch0 >= act_begin) rows(std::integral_constant<int, 1>{});
+                else if (ch0 + 32 <= act_begin) rows(std::integral_constant<int, 0>{});
+                else rows(std::integral_constant<int, 2>{});
             }
         }
         }
