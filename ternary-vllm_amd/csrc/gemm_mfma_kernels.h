@@ -388,8 +388,15 @@ __device__ unsigned long long tvl_clock_probe[8 * 4096];
 __device__ unsigned long long tvl_clock_probe_switch[2 * 4096];   // PERSIST: shader clocks spent in tile switches (stores included), and their count
 __device__ unsigned long long tvl_clock_probe_steps[4 * 256];      // shader clock at the start of the first 256 steps of workgroups 0..3 (wave 0; kept in LDS behind the tiles)
 #define TVL_STAMP(i) do { stamp_c[i] = __builtin_amdgcn_s_memtime(); stamp_r[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// clock-probe builds only: TVL_STEP_ABLATE removes parts of the 16x16x32 kernel's step (timing studies; results are wrong by construction):
+// 1 no activation LDS-DMA, 2 no weight loads, 4 no decode, 8 no fragment reads, 16 no matrix instructions, 32 no barrier
+#ifndef TVL_STEP_ABLATE
+#define TVL_STEP_ABLATE 0
+#endif
+#define TVL_ABLATED(bit) ((TVL_STEP_ABLATE & (bit)) != 0)
 #else
 #define TVL_STAMP(i) do { } while (0)
+#define TVL_ABLATED(bit) false
 #endif
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -497,6 +504,7 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
     set_load_tile(vb_l);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
     auto stage_a = [&](int kb, int buf) __attribute__((always_inline)) {
+        if constexpr (TVL_ABLATED(1)) return;
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + buf * A_TILE_BYTES + (i * NT + wid * 64) * 16);
@@ -528,6 +536,11 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         int kw = kb0 + kb;
         kw = kw >= w_steps ? kw - w_steps : kw;
         kw = kw >= w_steps ? kw - w_steps : kw;
+        if constexpr (TVL_ABLATED(2)) {
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) asm volatile("v_mov_b32 %0, %1" : "=v"(dst[t]) : "v"(b_off[t]));
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < NTL; ++t)
             asm volatile("global_load_dword %0, %1, %2" : "=v"(dst[t]) : "v"(b_off[t]), "s"(b_base + (int64_t)kw * (BK / 4)) : "memory");
@@ -575,11 +588,26 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
 
     auto read_a = [&](int buf, int s, int half, uint4 (&af)[MH]) __attribute__((always_inline)) {
         const unsigned char* abase = lds + buf * A_TILE_BYTES + a_row_off + a_col_off[s] + half * MH * 16 * ROW_BYTES;
+        if constexpr (TVL_ABLATED(8)) {
+#pragma unroll
+            for (int i = 0; i < MH; ++i) asm volatile("" : "=v"(af[i].x), "=v"(af[i].y), "=v"(af[i].z), "=v"(af[i].w));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MH; ++i) af[i] = *reinterpret_cast<const uint4*>(abase + i * 16 * ROW_BYTES);
     };
-    auto decode_b = [&](uint32_t d, int s) { return s ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc); };
+    auto decode_b = [&](uint32_t d, int s) {
+        if constexpr (TVL_ABLATED(4)) return make_uint4(d, d, d, d);
+        return s ? decode8<TX, 1>(d, dc) : decode8<TX, 0>(d, dc);
+    };
     auto mma = [&](const uint4 (&af)[MH], int half, const uint4 (&bf)[NTL]) __attribute__((always_inline)) {
+        if constexpr (TVL_ABLATED(16)) {
+#pragma unroll
+            for (int i = 0; i < MH; ++i) asm volatile("" :: "v"(af[i].x), "v"(af[i].y), "v"(af[i].z), "v"(af[i].w));
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) asm volatile("" :: "v"(bf[t].x), "v"(bf[t].y), "v"(bf[t].z), "v"(bf[t].w));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MH; ++i)
 #pragma unroll
@@ -849,7 +877,7 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         __builtin_amdgcn_sched_barrier(0);
         // ---- middle of the step: tile kb+1 (and its weights w1) complete, tile kb-1 retired ----
         wait_mid_step(w1);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!TVL_ABLATED(32)) __builtin_amdgcn_s_barrier();
         read_a(buf, 1, 1, afB);
         issue_loads(bufn, wn);
         __builtin_amdgcn_sched_barrier(0);

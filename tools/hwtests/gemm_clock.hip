@@ -18,19 +18,21 @@ using namespace tvl;
 static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
 // the mid-size path's split-K form: 128 x 128 tiles of four waves, `splits` k ranges per tile, raw float32 partial sums to slabs
-template <int NB, int WAVES_M = 1>
+template <int NB, int WAVES_M = 1, int BM = 128, int WAVES = 4 * WAVES_M>
 static void run_mid_split(int m, int n, int k, int splits, const f16* x, const uint8_t* pw, const float* sc, const float* bi, float* slab) {
     // WAVES_M = 2: eight waves of 64 rows x 32 channels on the same 128 x 128 tile (two waves per SIMD; each weight decoded twice)
-    auto kern = gemm_mfma16_kernel<f16, float, false, TVL_ACT_NONE, WAVES_M, false, NB, 128, 4 * WAVES_M, true, (WAVES_M == 2 ? 2 : 3)>;
-    const size_t lds = (size_t)NB * 128 * ROW_BYTES + 2048;   // + the step stamps
+    // BM = 64, WAVES = 8: a 64 x 256 tile (12 KiB of loads per step instead of 18: packed weights are cheap to load, activations are not)
+    constexpr int BN = 32 * WAVES / WAVES_M;
+    auto kern = gemm_mfma16_kernel<f16, float, false, TVL_ACT_NONE, WAVES_M, false, NB, BM, WAVES, true, (WAVES == 8 ? 2 : 3)>;
+    const size_t lds = (size_t)NB * BM * ROW_BYTES + 2048;   // + the step stamps
     CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int tiles_n = (n + 127) / 128, nblk = ((m + 127) / 128) * tiles_n, per = (k / 64 + splits - 1) / splits;
+    const int tiles_n = (n + BN - 1) / BN, nblk = ((m + BM - 1) / BM) * tiles_n, per = (k / 64 + splits - 1) / splits;
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     float ms = 0;
     for (int round = 0; round < 8; ++round) {
         CHECK(hipEventRecord(a, 0));
         for (int i = 0; i < 5000; ++i)
-            hipLaunchKernelGGL(kern, dim3(nblk, splits), dim3(256 * WAVES_M), lds, 0, x, m, k, (int64_t)k, pw, n, (int64_t)(k / 4), sc, bi, 100.0f, 0, slab, (int64_t)n,
+            hipLaunchKernelGGL(kern, dim3(nblk, splits), dim3(64 * WAVES), lds, 0, x, m, k, (int64_t)k, pw, n, (int64_t)(k / 4), sc, bi, 100.0f, 0, slab, (int64_t)n,
                                tiles_n, nblk, k / 64, per);
         CHECK(hipEventRecord(b, 0)); CHECK(hipEventSynchronize(b));
         CHECK(hipEventElapsedTime(&ms, a, b));
@@ -46,7 +48,7 @@ static void run_mid_split(int m, int n, int k, int splits, const f16* x, const u
         all_us.push_back((r[3] - r[0]) * 0.01);
         r_first = std::min(r_first, r[0]); r_last = std::max(r_last, r[3]);
     }
-    printf("128 x 128 tiles, %d waves, %d LDS tiles, %d tiles x %d k ranges of %d steps: %.2f us per launch (event pair)\n", 4 * WAVES_M, NB, nblk, splits, per, ms / 5000 * 1e3);
+    printf("%d x %d tiles, %d waves, %d LDS tiles, %d tiles x %d k ranges of %d steps: %.2f us per launch (event pair)\n", BM, BN, WAVES, NB, nblk, splits, per, ms / 5000 * 1e3);
     printf("  clock over the k loop %.3f GHz   prologue %.2f us   k loop %.2f us (%.0f cyc per step)   epilogue (slab stores) %.2f us   workgroup lifetime %.2f us\n",
            med(ghz), med(pro_us), med(loop_us), med(loopc) / per, med(epi_us), med(all_us));
     printf("  first workgroup entry to last workgroup exit (k range 0 only): %.2f us\n", (r_last - r_first) * 0.01);
@@ -156,7 +158,9 @@ int main(int argc, char** argv) {
         const int splits = argc > 5 ? atoi(argv[5]) : 4;
         float* slab; CHECK(hipMalloc(&slab, (size_t)splits * m * n * 4));
         const int nb = argc > 6 ? atoi(argv[6]) : 4;   // LDS tiles: a tile is requested nb - 2 steps before its use
-        if (nb == 14) run_mid_split<4, 2>(m, n, k, splits, x, pw, sc, bi, slab);   // lds_tiles = 14: four tiles, eight waves
+        if (nb == 24) run_mid_split<4, 1, 64, 8>(m, n, k, splits, x, pw, sc, bi, slab);   // lds_tiles = 24 / 26: 64 x 256 tiles of eight waves, four / six LDS tiles
+        else if (nb == 26) run_mid_split<6, 1, 64, 8>(m, n, k, splits, x, pw, sc, bi, slab);
+        else if (nb == 14) run_mid_split<4, 2>(m, n, k, splits, x, pw, sc, bi, slab);   // lds_tiles = 14: four tiles, eight waves
         else if (nb == 16) run_mid_split<6, 2>(m, n, k, splits, x, pw, sc, bi, slab);
         else if (nb == 6) run_mid_split<6>(m, n, k, splits, x, pw, sc, bi, slab);
         else if (nb == 5) run_mid_split<5>(m, n, k, splits, x, pw, sc, bi, slab);
