@@ -389,7 +389,8 @@ __device__ unsigned long long tvl_clock_probe_switch[2 * 4096];   // PERSIST: sh
 __device__ unsigned long long tvl_clock_probe_steps[4 * 256];      // shader clock at the start of the first 256 steps of workgroups 0..3 (wave 0; kept in LDS behind the tiles)
 #define TVL_STAMP(i) do { stamp_c[i] = __builtin_amdgcn_s_memtime(); stamp_r[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // clock-probe builds only: TVL_STEP_ABLATE removes parts of the 16x16x32 kernel's step (timing studies; results are wrong by construction):
-// 1 no activation LDS-DMA, 2 no weight loads, 4 no decode, 8 no fragment reads, 16 no matrix instructions, 32 no barrier
+// 1 no activation LDS-DMA, 2 no weight loads, 4 no decode, 8 no fragment reads, 16 no matrix instructions, 32 no barrier, 64 the barrier in every
+// second step only (four LDS tiles)
 #ifndef TVL_STEP_ABLATE
 #define TVL_STEP_ABLATE 0
 #endif
@@ -877,7 +878,7 @@ gemm_mfma16_kernel(const TX* __restrict__ x, int m, int k, int64_t ld_x, const u
         __builtin_amdgcn_sched_barrier(0);
         // ---- middle of the step: tile kb+1 (and its weights w1) complete, tile kb-1 retired ----
         wait_mid_step(w1);
-        if constexpr (!TVL_ABLATED(32)) __builtin_amdgcn_s_barrier();
+        if constexpr (!TVL_ABLATED(32) && !(TVL_ABLATED(64) && (buf & 1))) __builtin_amdgcn_s_barrier();
         read_a(buf, 1, 1, afB);
         issue_loads(bufn, wn);
         __builtin_amdgcn_sched_barrier(0);
