@@ -418,6 +418,10 @@ __device__ __forceinline__ floatx4 mfma16(uint4 a, uint4 b, floatx4 c) {
 // NB = LDS tiles: 3 = a tile is requested one step (~1.3 us) before its use, enough for operands that sit in the
 // Infinity Cache; 4 = two steps ahead (the wait at mid-step leaves the newer group of loads in flight: counted vmcnt),
 // which also covers activations that come cold from HBM.
+// With 16-bit outputs it also requests the next tile's scale / bias values by LDS-DMA at every tile switch (stage_params: 512 bytes per
+// wave behind the activation tiles, persist_param_lds_bytes), so a tile's epilogue starts without a trip to memory, and writes its
+// tiles with plain stores.
+// WAVES_M / WN_ / BM_ / WAVES: WAVES_M x (WAVES / WAVES_M) waves of (BM_ / WAVES_M) rows x WN_ channels each; every shipped form has WAVES_M = 1:
 // BM_ / WAVES: the workgroup tile is BM_ rows x 32 * WAVES channels (one wave per 32 channels, every wave all BM_ rows): 256 x 256
 // with 8 waves is the big tile; 256 x 128 and 128 x 128 with 4 waves serve problems with fewer rows, where a 256-wide tile
 // would leave compute units idle.  SPLIT: blockIdx.y selects a range of k steps and the raw float32 partial sums go to slab
@@ -426,6 +430,9 @@ __device__ __forceinline__ floatx4 mfma16(uint4 a, uint4 b, floatx4 c) {
 // the 256 x 256 tile's 1.6 us step gets by with 3 (measured: 128 x 128 at M = 1024: 47.9 -> 36.5 us from NB = 3 to 4; 5 and 6 add
 // nothing).  (Tried and dropped: two 4-wave groups per workgroup taking alternate k steps of one tile with an exchange of
 // half the accumulators through LDS at the end - no faster than one group with NB = 4.)
+// PARTS: phases per MFMA group of a step.  2 = four phases of MT / 2 row tiles; 4 = eight phases of MT / 4 (fewer fragment registers,
+// which is what lets the persistent 256 x 256 form keep a fourth weight register set).
+
 // dynamic LDS the persistent form needs beyond its NB activation tiles (the staged scale / bias values)
 constexpr int persist_param_lds_bytes(int waves) { return 512 * waves; }
 
