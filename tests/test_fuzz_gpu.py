@@ -89,3 +89,10 @@ def test_matmul_random_large_shapes(ops, dev, c_oracle, seed):
     rows = torch.randint(0, m, (8,), generator=g)
     want = O.ternary_matmul(x[rows].numpy(), pw.cpu().numpy(), scale.numpy(), bias.numpy(), 100.0)
     assert np.array_equal(y[rows.to(dev)].cpu().numpy(), want)
+    # 16-bit outputs with a clip that binds (inner tiles: the short epilogue, clip after the rounding for float16; edge tiles: the
+    # general one), with and without bias: one rounding of the reference's float32 value
+    del y, ref
+    for b in (bias, None):
+        y16 = ops.ternary_matmul(x.to(dev).to(xdt), pw, scale.to(dev), None if b is None else b.to(dev), 2.0, out_dtype=xdt)
+        ref16 = torch.from_numpy(c_oracle(x.numpy(), pw.cpu().numpy(), scale.numpy(), None if b is None else b.numpy(), 2.0)).to(xdt)
+        assert torch.equal(y16.cpu(), ref16), f"m={m} n={n} k={k} {xdt} 16-bit out, bias={b is not None}"
