@@ -62,8 +62,11 @@ def test_matmul_random_configurations(ops, dev, seed):
         g = got.float().cpu().numpy()
         w = torch.from_numpy(want).to(ydt).float().numpy()       # the oracle's float32 result rounded once to the output type
         if gelu:
-            tol = 1e-5 if ydt == torch.float32 else 2e-2
-            assert np.max(np.abs(g - w)) <= tol, tag
+            if ydt == torch.float32:
+                assert np.max(np.abs(g - w)) <= 1e-5, tag
+            else:   # 16-bit outputs: the float32 values agree to 1e-5, so the rounded ones differ by at most one unit in the last place
+                ulp = np.exp2(np.floor(np.log2(np.maximum(np.abs(w), 2.0 ** -14))) - (10 if ydt == torch.float16 else 7))
+                assert np.all(np.abs(g - w) <= ulp + 1e-5), tag
         else:
             assert np.array_equal(g, w), tag
 
